@@ -1,0 +1,225 @@
+/*
+ * rtamd.h -- C-ABI of the MI355X ray-intersection + shading hot path.
+ *
+ * The reference program (R/ = HAI719I_Raytracer/) has no FFI layer: main.cpp calls C++ member
+ * functions of Scene / Camera / Mesh directly.  This header is the boundary a maintainer binds
+ * at those call sites; every entry point names the reference interface it stands in for.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a negative
+ * RT_E_* code on failure (rt_last_error() gives the text); no exceptions cross the boundary;
+ * output buffers are caller-owned; calls are blocking unless the name ends in _device (then
+ * the work is enqueued on the given HIP stream and the pointers are device pointers);
+ * thread-compatible, not thread-safe; one process drives one GPU (rt_init picks it).
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------ */
+#define RT_OK 0
+#define RT_E_INVALID (-1)   /* bad argument / descriptor                                   */
+#define RT_E_NOINIT (-2)    /* rt_init not called                                          */
+#define RT_E_HIP (-3)       /* a HIP runtime call failed (no GPU, out of memory, fault ..) */
+#define RT_E_HANDLE (-4)    /* unknown scene handle                                        */
+#define RT_E_LIMIT (-5)     /* size beyond a documented limit                              */
+
+/* ---- object type codes: R/src/Scene.h:20-22 (MESH 0, SPHERE 1, SQUARE 2) ------------------ */
+#define RT_MESH 0
+#define RT_SPHERE 1
+#define RT_SQUARE 2
+
+/* ---- material type codes: R/src/Material.h:10-14 ----------------------------------------- */
+#define RT_MAT_DIFFUSE 0
+#define RT_MAT_GLASS 1
+#define RT_MAT_MIRROR 2
+
+/* ---- light type codes: R/src/Scene.h:26-29 ------------------------------------------------ */
+#define RT_LIGHT_SPHERICAL 0
+#define RT_LIGHT_QUAD 1
+
+/* ---- RNG modes --------------------------------------------------------------------------- */
+#define RT_RNG_COUNTER 0 /* seeded counter-based generator (rt_rand31 below)                */
+#define RT_RNG_LIBC 1    /* glibc rand() from srand(1): CPU oracle only (sequential stream) */
+
+/* Material: R/src/Material.h:17-34.  shininess is the reference's double narrowed to float the
+ * way Scene::getMaterialProperties does (R/src/Scene.h:283-301). */
+typedef struct rt_material {
+    float diffuse[3];
+    float specular[3];
+    float shininess;
+    float index_medium;
+    int32_t type; /* RT_MAT_* */
+} rt_material;
+
+/* Sphere: R/src/Sphere.h:36-42 (m_center, m_radius) + its Mesh::material. */
+typedef struct rt_sphere {
+    float center[3];
+    float radius;
+    int32_t material; /* index into rt_scene_desc.materials */
+} rt_sphere;
+
+/* Square: the four vertices.position written by Square::setQuad and the Mesh transforms
+ * (R/src/Square.h:30-61, R/src/Mesh.h:128-173).  intersect reads 0,1,3; the kd builder 0..2;
+ * computeGlobalAABB all four. */
+typedef struct rt_square {
+    float v[4][3];
+    int32_t material;
+} rt_square;
+
+/* Mesh: a slice of the shared vertex / triangle pools.  aabb_* is Mesh::aabb
+ * (R/src/Mesh.h:108): (+inf, -inf) until Mesh::computeAABB ran, exactly as in the reference. */
+typedef struct rt_mesh {
+    uint32_t first_vertex, n_vertices;     /* into positions / normals (xyz triples)        */
+    uint32_t first_triangle, n_triangles;  /* into triangles (index triples, mesh-local)    */
+    int32_t material;
+    float aabb_min[3], aabb_max[3];
+} rt_mesh;
+
+/* Light: R/src/Scene.h:32-46.  For a quad light only triangle (0,1,2) of Light::quad is ever
+ * sampled (R/src/Scene.h:271-275), so p0..p2 are those three vertex positions. */
+typedef struct rt_light {
+    int32_t type; /* RT_LIGHT_* */
+    float pos[3];
+    float color[3]; /* Light::material */
+    float p0[3], p1[3], p2[3];
+} rt_light;
+
+/* Flat scene: the state a reference Scene holds after a setup_* call. */
+typedef struct rt_scene_desc {
+    uint32_t n_spheres, n_squares, n_meshes, n_lights, n_materials;
+    const rt_sphere* spheres;
+    const rt_square* squares;
+    const rt_mesh* meshes;
+    const rt_light* lights;
+    const rt_material* materials;
+    uint32_t n_vertices, n_triangles;
+    const float* positions;    /* 3 * n_vertices                                             */
+    const float* normals;      /* 3 * n_vertices (Mesh::recomputeNormals output)             */
+    const uint32_t* triangles; /* 3 * n_triangles, indices local to the owning mesh          */
+    /* kd-tree parameters: R/src/Scene.h:96-100 (15, 30, 0.01f) */
+    int32_t kd_max_depth;
+    int32_t kd_max_leaf;
+    float kd_epsilon;
+} rt_scene_desc;
+
+/* Camera state as the reference leaves it in OpenGL: the PROJECTION and MODELVIEW matrices
+ * (column-major float, what glGetDoublev widens to double in R/src/matrixUtilities.h:188-217)
+ * and GL_DEPTH_RANGE near. */
+typedef struct rt_camera {
+    float projection[16];
+    float modelview[16];
+    float depth_near;
+} rt_camera;
+
+/* One closest-hit record = what Scene::computeIntersection (R/src/Scene.h:169-205) and
+ * Mesh::intersect (R/src/Mesh.h:206-281) return that is well defined. */
+typedef struct rt_hit {
+    int32_t hit;    /* intersectionExists                                                   */
+    int32_t type;   /* RT_MESH / RT_SPHERE / RT_SQUARE, -1 on a miss                        */
+    int32_t object; /* objectIndex, -1 on a miss                                            */
+    int32_t tri;    /* tIndex of the closest triangle for a mesh hit, else -1               */
+    float t;        /* FLT_MAX on a miss                                                    */
+    float p[3];
+    float n[3];
+    float pad_;
+} rt_hit;
+
+typedef struct rt_stats {
+    uint64_t rays;        /* closest-hit queries issued (primary + shadow + bounce)         */
+    uint64_t samples;     /* primary samples traced                                         */
+    uint64_t nodes;       /* shaded path nodes                                              */
+    double kernel_ms;     /* device time of the render kernels (HIP events on the stream)   */
+} rt_stats;
+
+typedef uint64_t rt_scene_t;
+
+/* ---- shared counter-based RNG -------------------------------------------------------------
+ * Replaces the reference's unseeded rand() (R/main.cpp:186-187, R/src/Scene.h:259-260).
+ * A sample is identified by (seed, pixel = x + y*w, sample index s); the k-th rand() call the
+ * reference would make while tracing that sample returns rt_rand31(rt_rng_key(..), k), a value
+ * in [0, 2^31) like rand().  Integer-only, so CPU and GPU agree bit for bit. */
+static inline uint32_t rt_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+static inline uint32_t rt_rng_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    return rt_mix32(seed ^ rt_mix32(pixel ^ rt_mix32(sample + 0x9E3779B9U)));
+}
+static inline uint32_t rt_rand31(uint32_t key, uint32_t k) {
+    return rt_mix32(key + k * 0x9E3779B9U) >> 1;
+}
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* Select HIP device `device` for this process and create the library's stream.
+ * No reference counterpart (the reference has no device). */
+int rt_init(int device);
+int rt_shutdown(void);
+const char* rt_last_error(void);
+
+/* ---- scene -------------------------------------------------------------------------------- */
+/* Copy the scene, build the object-level kd-tree (R/src/KDTree.cpp:363-519, done on the host as
+ * Scene::buildKDTree does) and the per-mesh triangle BVH, upload everything.  Stands in for the
+ * state left by Scene::setup_* + Scene::buildKDTree (R/src/Scene.h:112-115, 722-1048). */
+int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out);
+int rt_scene_destroy(rt_scene_t scene);
+
+/* Flattened object kd-tree, for inspection / parity tests.  nodes: 8 int32 per node
+ * {is_leaf, axis, cut(float bits), left, right, first_ref, n_refs, depth}; refs: 2 int32 per
+ * reference {type, object}; root_box: min xyz, max xyz.  Pass NULL buffers to query counts. */
+int rt_scene_kdtree(rt_scene_t scene, int32_t* nodes, uint32_t* n_nodes, int32_t* refs,
+                    uint32_t* n_refs, float root_box[6]);
+
+/* ---- batch closest hit: Scene::computeIntersection (R/src/Scene.h:169-205) over n rays ------
+ * org/dir: 3*n floats.  dir is normalised by the callee the way the Ray constructor does
+ * (R/src/Line.h:13-16), so pass what the reference passes to Ray(o, d). */
+int rt_intersect(rt_scene_t scene, const float* org, const float* dir, size_t n, rt_hit* out);
+int rt_intersect_device(rt_scene_t scene, const float* d_org, const float* d_dir, size_t n,
+                        rt_hit* d_out, void* hip_stream);
+
+/* ---- batch Mesh::intersect (R/src/Mesh.h:206-281) of mesh `mesh` alone: exposes tIndex ------ */
+int rt_mesh_intersect(rt_scene_t scene, uint32_t mesh, const float* org, const float* dir,
+                      size_t n, rt_hit* out);
+
+/* ---- primary rays: screen_space_to_world_space_ray (R/src/matrixUtilities.h:218-222) --------
+ * u, v: n floats each; org/dir: 3*n floats out (dir normalised once, as that function leaves it). */
+int rt_generate_rays(const rt_camera* cam, const float* u, const float* v, size_t n, float* org,
+                     float* dir);
+
+/* ---- batch Scene::rayTrace (R/src/Scene.h:716-720) under the counter RNG -------------------
+ * Ray i is traced as sample (pixel[i], sample[i]); its rand() calls start at index k0 (2 when the
+ * two jitter draws of R/main.cpp:186-187 precede it, 0 otherwise).  rgb: 3*n floats. */
+int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, const uint32_t* pixel,
+             const uint32_t* sample, uint32_t seed, uint32_t k0, float* rgb, rt_stats* stats);
+
+/* ---- full render: ray_trace_from_camera (R/main.cpp:170-221) without the PPM write ---------
+ * The image is cut into tile_w x tile_h pixel tiles, numbered row-major; this call renders the
+ * tiles t with t % world == rank (rank 0, world 1 = whole image).  Output is tile-major:
+ * local tile j (global tile rank + j*world) occupies floats [j*tile_w*tile_h*3, ...), row-major
+ * RGB inside the tile; pixels outside the image are 0.  rgb_tiles must hold
+ * rt_tiles_per_rank(..)*tile_w*tile_h*3 floats. */
+size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
+                         uint32_t world);
+int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp,
+              uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
+              float* rgb_tiles, rt_stats* stats);
+int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp,
+                     uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
+                     uint32_t world, float* d_rgb_tiles, uint64_t* d_counters3, void* hip_stream);
+
+/* Scatter `world` gathered tile buffers (rank-major, each padded to max_tiles_per_rank tiles)
+ * into a row-major w*h*3 image.  Host helper for the gather step. */
+int rt_tiles_to_image(const float* gathered, uint32_t w, uint32_t h, uint32_t tile_w,
+                      uint32_t tile_h, uint32_t world, float* rgb_image);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

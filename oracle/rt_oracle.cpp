@@ -1,0 +1,1071 @@
+/*
+ * rt_oracle.cpp -- CPU restatement of the reference ray tracer's intersection + shading path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing that ships (the HIP library, its host API, the drivers)
+ * may include, link, load or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker.
+ *
+ * What it is: a plain, single-translation-unit C++ restatement of the algorithm in
+ * R/ = HAI719I_Raytracer/ (main.cpp, the src headers, src/KDTree.cpp, src/Mesh.cpp).  Every routine
+ * cites the reference lines it follows and keeps their float evaluation order, because the
+ * reference is built with `g++ -O3` on x86-64 without -march / -ffast-math (R/Makefile:22-27):
+ * plain IEEE binary32 operations, no fused multiply-add.  Build this file the same way
+ * (see oracle/Makefile: -O2 -ffp-contract=off, no -march, no -ffast-math).
+ *
+ * Pinning: the reference itself cannot be built here (its hot-path headers include
+ * <GL/glut.h>, which this image lacks), so the oracle is pinned by the one known answer the
+ * reference ships: R/rendu.ppm, the 480x480 / 50 spp render of scene 3 (Cornell box + star
+ * mesh) under the unseeded glibc rand().  tests/test_oracle_kat.py renders that case with
+ * orc_render(RT_RNG_LIBC) and requires all 230 400 pixels to match byte for byte.
+ *
+ * Third-party pieces the reference calls but does not contain, restated from their published
+ * algorithms: gluPerspective and the fixed-function matrix stack of OpenGL (SGI libGLU /
+ * Mesa math, float storage) -- see camera_matrices(); glibc rand()/powf/sqrt are simply called.
+ */
+#include "../include/rtamd.h"
+#include "../include/rt_flops.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+const float INF = std::numeric_limits<float>::infinity();
+
+/* ----------------------------------------------------------------------------------------
+ * float[3] helpers.  R/src/Vec3.h:12-119.  Every product / sum is its own binary32 operation,
+ * sums run left to right.
+ * -------------------------------------------------------------------------------------- */
+struct V3 {
+    float v[3];
+    V3() : v{0.f, 0.f, 0.f} {}
+    V3(float a, float b, float c) : v{a, b, c} {}
+    float operator[](int i) const { return v[i]; }
+    float& operator[](int i) { return v[i]; }
+};
+inline V3 from3(const float* p) { return V3(p[0], p[1], p[2]); }
+inline V3 add(const V3& a, const V3& b) { return V3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+inline V3 sub(const V3& a, const V3& b) { return V3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline V3 mul(float s, const V3& a) { return V3(s * a[0], s * a[1], s * a[2]); } /* :103-108 */
+inline V3 divs(const V3& a, float s) { return V3(a[0] / s, a[1] / s, a[2] / s); } /* :109 */
+inline float dot(const V3& a, const V3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline V3 cross(const V3& a, const V3& b) { /* :38-42 */
+    return V3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+/* length(): the reference calls the C `sqrt` on a float (:29); a double sqrt rounded to float is
+ * the correctly rounded binary32 root, which is what sqrtf returns. */
+inline float length(const V3& a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline void normalize(V3& a) { /* :34 -- three true divides */
+    float L = length(a);
+    a[0] /= L; a[1] /= L; a[2] /= L;
+}
+/* std::max / std::min exactly as libstdc++ defines them (they matter for NaN) */
+inline float smax(float a, float b) { return (a < b) ? b : a; }
+inline float smin(float a, float b) { return (b < a) ? b : a; }
+
+/* ----------------------------------------------------------------------------------------
+ * Event counters behind the FLOP-per-ray figure (include/rt_flops.h).
+ * -------------------------------------------------------------------------------------- */
+struct Counters {
+    uint64_t rays = 0, samples = 0, nodes = 0;
+    uint64_t aabb = 0, sph_miss = 0, sph_hit = 0, sq_behind = 0, sq_reject = 0, sq_hit = 0;
+    uint64_t tri_par = 0, tri_u = 0, tri_v = 0, tri_full = 0, tri_upd = 0, leaf_refs = 0;
+    uint64_t light_samples = 0;
+    void operator+=(const Counters& o) {
+        rays += o.rays; samples += o.samples; nodes += o.nodes; aabb += o.aabb;
+        sph_miss += o.sph_miss; sph_hit += o.sph_hit; sq_behind += o.sq_behind;
+        sq_reject += o.sq_reject; sq_hit += o.sq_hit; tri_par += o.tri_par; tri_u += o.tri_u;
+        tri_v += o.tri_v; tri_full += o.tri_full; tri_upd += o.tri_upd;
+        leaf_refs += o.leaf_refs; light_samples += o.light_samples;
+    }
+    double flops() const {
+        return double(aabb) * RT_FLOP_AABB + double(sph_miss) * RT_FLOP_SPHERE_MISS +
+               double(sph_hit) * RT_FLOP_SPHERE_HIT + double(sq_behind) * RT_FLOP_SQUARE_BEHIND +
+               double(sq_reject) * RT_FLOP_SQUARE_REJECT + double(sq_hit) * RT_FLOP_SQUARE_HIT +
+               double(tri_par) * RT_FLOP_TRI_PARALLEL + double(tri_u) * RT_FLOP_TRI_U_OUT +
+               double(tri_v) * RT_FLOP_TRI_V_OUT + double(tri_full) * RT_FLOP_TRI_TESTED +
+               double(tri_upd) * RT_FLOP_TRI_UPDATE + double(leaf_refs) * RT_FLOP_LEAF_REF +
+               double(light_samples) * RT_FLOP_LIGHT_SAMPLE;
+    }
+};
+
+/* ----------------------------------------------------------------------------------------
+ * Scene storage (deep copy of an rt_scene_desc) + the object-level kd-tree.
+ * -------------------------------------------------------------------------------------- */
+struct Box { V3 lo{INF, INF, INF}, hi{-INF, -INF, -INF}; }; /* R/src/AABB.h:14-26 */
+
+struct Ref { int type; int object; }; /* R/src/PrimitiveRef.h; type uses RT_* object codes */
+
+struct KdNode { /* R/src/KDTree.h:12-29 */
+    Box box;
+    int axis = -1;
+    float cut = 0.f;
+    int left = -1, right = -1;
+    bool leaf = false;
+    int depth = 0;
+    std::vector<Ref> refs;
+};
+
+struct OScene {
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_square> squares;
+    std::vector<rt_mesh> meshes;
+    std::vector<rt_light> lights;
+    std::vector<rt_material> materials;
+    std::vector<float> positions, normals;
+    std::vector<uint32_t> triangles;
+    int kd_max_depth = 15, kd_max_leaf = 30;
+    float kd_epsilon = 0.01f;
+    std::vector<KdNode> kd; /* kd[0] = root, children stored in pre-order */
+    rt_scene_desc desc{};   /* view of the vectors above */
+
+    void refresh_desc() {
+        desc.n_spheres = (uint32_t)spheres.size(); desc.spheres = spheres.data();
+        desc.n_squares = (uint32_t)squares.size(); desc.squares = squares.data();
+        desc.n_meshes = (uint32_t)meshes.size(); desc.meshes = meshes.data();
+        desc.n_lights = (uint32_t)lights.size(); desc.lights = lights.data();
+        desc.n_materials = (uint32_t)materials.size(); desc.materials = materials.data();
+        desc.n_vertices = (uint32_t)(positions.size() / 3);
+        desc.n_triangles = (uint32_t)(triangles.size() / 3);
+        desc.positions = positions.data(); desc.normals = normals.data();
+        desc.triangles = triangles.data();
+        desc.kd_max_depth = kd_max_depth; desc.kd_max_leaf = kd_max_leaf;
+        desc.kd_epsilon = kd_epsilon;
+    }
+};
+
+inline void expand(Box& b, const V3& p) { /* R/src/AABB.h:76-84 */
+    for (int a = 0; a < 3; ++a) { b.lo[a] = smin(b.lo[a], p[a]); b.hi[a] = smax(b.hi[a], p[a]); }
+}
+
+/* Scene::computeGlobalAABB, R/src/Scene.h:133-166: meshes, then squares (all 4 vertices), then
+ * spheres (centre -/+ radius). */
+Box global_box(const OScene& s) {
+    Box b;
+    for (const rt_mesh& m : s.meshes)
+        for (uint32_t i = 0; i < m.n_vertices; ++i) expand(b, from3(&s.positions[3 * (m.first_vertex + i)]));
+    for (const rt_square& q : s.squares)
+        for (int i = 0; i < 4; ++i) expand(b, from3(q.v[i]));
+    for (const rt_sphere& sp : s.spheres) {
+        V3 c = from3(sp.center);
+        expand(b, V3(c[0] - sp.radius, c[1] - sp.radius, c[2] - sp.radius));
+        expand(b, V3(c[0] + sp.radius, c[1] + sp.radius, c[2] + sp.radius));
+    }
+    return b;
+}
+
+/* Bounding box the kd builder gives one object: R/src/KDTree.cpp:393-416 (and again :425-447). */
+Box ref_box(const OScene& s, const Ref& r) {
+    Box b;
+    if (r.type == RT_SPHERE) {
+        const rt_sphere& sp = s.spheres[r.object];
+        V3 c = from3(sp.center), rr(sp.radius, sp.radius, sp.radius);
+        b.lo = sub(c, rr); b.hi = add(c, rr);
+    } else if (r.type == RT_SQUARE) { /* vertices 0..2 only (:403-409) */
+        const rt_square& q = s.squares[r.object];
+        b.lo = b.hi = from3(q.v[0]);
+        for (int v = 1; v < 3; ++v)
+            for (int d = 0; d < 3; ++d) {
+                if (q.v[v][d] < b.lo[d]) b.lo[d] = q.v[v][d];
+                if (q.v[v][d] > b.hi[d]) b.hi[d] = q.v[v][d];
+            }
+    } else { /* Mesh::aabb as stored, possibly still (+inf,-inf) (:413) */
+        const rt_mesh& m = s.meshes[r.object];
+        b.lo = from3(m.aabb_min); b.hi = from3(m.aabb_max);
+    }
+    return b;
+}
+
+/* KDTree::buildNode V3, R/src/KDTree.cpp:363-473. */
+int kd_build(OScene& s, const Box& box, const std::vector<Ref>& refs, int depth) {
+    int id = (int)s.kd.size();
+    s.kd.emplace_back();
+    s.kd[id].box = box;
+    s.kd[id].depth = depth;
+    auto make_leaf = [&]() { s.kd[id].leaf = true; s.kd[id].refs = refs; return id; };
+    if ((long)refs.size() <= (long)s.kd_max_leaf || depth >= s.kd_max_depth) return make_leaf();
+    float sx = box.hi[0] - box.lo[0], sy = box.hi[1] - box.lo[1], sz = box.hi[2] - box.lo[2];
+    if (smax(smax(sx, sy), sz) < s.kd_epsilon) return make_leaf(); /* std::max({..}) :379 */
+    int axis = 0;
+    if (sy >= sx && sy >= sz) axis = 1;
+    else if (sz >= sx && sz >= sy) axis = 2;
+    s.kd[id].axis = axis;
+    float cut = 0.f;
+    for (const Ref& r : refs) { Box b = ref_box(s, r); cut += (b.lo[axis] + b.hi[axis]) * 0.5f; }
+    cut /= refs.size(); /* float /= size_t -> float / (float)size */
+    s.kd[id].cut = cut;
+    std::vector<Ref> L, R;
+    for (const Ref& r : refs) {
+        Box b = ref_box(s, r);
+        float centre = 0.5f * (b.lo[axis] + b.hi[axis]);
+        if (centre <= cut) L.push_back(r); else R.push_back(r);
+    }
+    if (L.empty() || R.empty()) return make_leaf();
+    Box bl = box, br = box;
+    bl.hi[axis] = cut; br.lo[axis] = cut;
+    int l = kd_build(s, bl, L, depth + 1);
+    int r = kd_build(s, br, R, depth + 1);
+    s.kd[id].left = l; s.kd[id].right = r;
+    return id;
+}
+
+/* KDTree::buildKDTree, R/src/KDTree.cpp:477-519: spheres, squares, meshes in that order. */
+void kd_build_scene(OScene& s) {
+    s.kd.clear();
+    std::vector<Ref> all;
+    for (int i = 0; i < (int)s.spheres.size(); ++i) all.push_back({RT_SPHERE, i});
+    for (int i = 0; i < (int)s.squares.size(); ++i) all.push_back({RT_SQUARE, i});
+    for (int i = 0; i < (int)s.meshes.size(); ++i) all.push_back({RT_MESH, i});
+    kd_build(s, global_box(s), all, 0);
+}
+
+/* ----------------------------------------------------------------------------------------
+ * Rays and hits.
+ * -------------------------------------------------------------------------------------- */
+struct Ray { /* R/src/Line.h:13-16 + R/src/Ray.h: the constructor normalises the direction */
+    V3 o, d;
+    Ray(const V3& o_, const V3& d_) : o(o_), d(d_) { normalize(d); }
+};
+
+struct Hit { /* R/src/Hit.h + the fields of rt_hit */
+    bool hit = false;
+    float t = INF;
+    V3 p, n;
+    int type = -1, object = -1, tri = -1;
+};
+
+/* AABB::intersectRayAABB, R/src/AABB.h:30-73. */
+bool box_hit(const Box& b, const Ray& r, float& t_in, float& t_out, Counters& c) {
+    ++c.aabb;
+    t_in = -INF; t_out = INF;
+    for (int a = 0; a < 3; ++a) {
+        float o = r.o[a], d = r.d[a], lo = b.lo[a], hi = b.hi[a];
+        if (std::fabs(d) < 1e-8f) {
+            if (o < lo || o > hi) return false;
+            continue;
+        }
+        float t1 = (lo - o) / d, t2 = (hi - o) / d;
+        if (t1 > t2) std::swap(t1, t2);
+        t_in = smax(t_in, t1);
+        t_out = smin(t_out, t2);
+        if (t_in > t_out) return false;
+    }
+    return t_out >= 0.0f;
+}
+
+/* Sphere::intersect, R/src/Sphere.h:85-162. */
+bool sphere_hit(const rt_sphere& sp, const Ray& r, Hit& h, Counters& c) {
+    V3 ctr = from3(sp.center);
+    V3 oc = sub(r.o, ctr);
+    float a = dot(r.d, r.d);
+    float b = dot(mul(2.f, r.d), oc);
+    float n = length(oc);
+    float cc = (n * n) - (sp.radius * sp.radius);
+    float delta = b * b - 4 * a * cc;
+    float t;
+    if (delta > 0) {
+        ++c.sph_hit;
+        float sq = std::sqrt(delta);
+        float a2 = 2 * a;
+        float t1 = (-b - sq) / a2, t2 = (-b + sq) / a2;
+        if (t1 > 0 && t2 > 0) t = smin(t1, t2);
+        else if (t1 > 0) t = t1;
+        else if (t2 > 0) t = t2;
+        else return false;
+    } else if (delta == 0) {
+        ++c.sph_hit;
+        t = -b / (2 * a);
+        if (!(t > 0)) return false;
+    } else {
+        ++c.sph_miss;
+        return false;
+    }
+    h.hit = true;
+    h.t = t;
+    h.p = add(r.o, mul(t, r.d));
+    h.n = sub(h.p, ctr);
+    normalize(h.n);
+    return true;
+}
+
+/* Square::intersect, R/src/Square.h:63-115.  When t is NaN the reference leaves
+ * intersectionExists uninitialised (neither branch runs); the restatement reports a miss and
+ * the tests keep such rays on the grazing list. */
+bool square_hit(const rt_square& q, const Ray& r, Hit& h, Counters& c) {
+    V3 v0 = from3(q.v[0]);
+    V3 w = sub(from3(q.v[1]), v0), hh = sub(from3(q.v[3]), v0);
+    V3 n = cross(w, hh);
+    float t = dot(sub(v0, r.o), n) / dot(r.d, n);
+    if (t < 0) { ++c.sq_behind; return false; }
+    if (t >= 0) {
+        V3 p = add(r.o, mul(t, r.d));
+        V3 bp = sub(p, v0);
+        float width = length(w), height = length(hh);
+        float pw = dot(bp, w) / width, ph = dot(bp, hh) / height;
+        if (0 < pw && pw < width && 0 < ph && ph < height) {
+            ++c.sq_hit;
+            h.hit = true; h.t = t; h.p = p; h.n = n;
+            normalize(h.n);
+            return true;
+        }
+        ++c.sq_reject;
+        return false;
+    }
+    ++c.sq_behind;
+    return false; /* t is NaN: undefined in the reference */
+}
+
+/* Mesh::intersect, R/src/Mesh.h:206-281: brute force over the triangles in index order. */
+bool mesh_hit(const OScene& s, const rt_mesh& m, const Ray& r, Hit& h, Counters& c) {
+    const float scaling = 1.000001f;
+    const float* P = &s.positions[3 * m.first_vertex];
+    const float* N = &s.normals[3 * m.first_vertex];
+    const uint32_t* T = &s.triangles[3 * m.first_triangle];
+    bool found = false;
+    float best = FLT_MAX;
+    for (uint32_t i = 0; i < m.n_triangles; ++i) {
+        uint32_t i0 = T[3 * i], i1 = T[3 * i + 1], i2 = T[3 * i + 2];
+        V3 v0 = mul(scaling, from3(P + 3 * i0)), v1 = mul(scaling, from3(P + 3 * i1)),
+           v2 = mul(scaling, from3(P + 3 * i2));
+        V3 e1 = sub(v1, v0), e2 = sub(v2, v0);
+        V3 hv = cross(r.d, e2);
+        float a = dot(e1, hv);
+        if (std::fabs(a) < 1e-6f) { ++c.tri_par; continue; }
+        float f = 1.0f / a;
+        V3 sv = sub(r.o, v0);
+        float u = f * dot(sv, hv);
+        if (u < 0.0f || u > 1.0f) { ++c.tri_u; continue; }
+        V3 qv = cross(sv, e1);
+        float v = f * dot(r.d, qv);
+        if (v < 0.0f || u + v > 1.0f) { ++c.tri_v; continue; }
+        float t = f * dot(e2, qv);
+        ++c.tri_full;
+        if (t > 1e-6f && t < best) {
+            ++c.tri_upd;
+            best = t;
+            found = true;
+            h.hit = true; h.t = t; h.tri = (int)i;
+            h.p = add(r.o, mul(t, r.d));
+            V3 nn = add(add(mul(1.0f - u - v, from3(N + 3 * i0)), mul(u, from3(N + 3 * i1))),
+                        mul(v, from3(N + 3 * i2)));
+            normalize(nn);
+            h.n = nn;
+        }
+    }
+    return found;
+}
+
+/* KDTree::intersectPrimitive, R/src/KDTree.cpp:522-579. */
+bool ref_hit(const OScene& s, const Ref& rf, const Ray& r, Hit& h, Counters& c) {
+    bool ok;
+    if (rf.type == RT_SPHERE) ok = sphere_hit(s.spheres[rf.object], r, h, c);
+    else if (rf.type == RT_SQUARE) ok = square_hit(s.squares[rf.object], r, h, c);
+    else ok = mesh_hit(s, s.meshes[rf.object], r, h, c);
+    if (ok) { h.type = rf.type; h.object = rf.object; }
+    return ok;
+}
+
+/* KDTree::intersectNode, R/src/KDTree.cpp:582-677. */
+bool kd_node_hit(const OScene& s, int id, const Ray& r, float t_in, float t_out, Hit& best, Counters& c) {
+    const KdNode& nd = s.kd[id];
+    if (nd.leaf) {
+        bool any = false;
+        for (const Ref& rf : nd.refs) {
+            ++c.leaf_refs;
+            Hit tmp;
+            if (ref_hit(s, rf, r, tmp, c)) {
+                any = true;
+                if (!best.hit || tmp.t < best.t) best = tmp;
+            }
+        }
+        return any;
+    }
+    int axis = nd.axis;
+    float t_split;
+    if (std::fabs(r.d[axis]) < s.kd_epsilon) t_split = INF; /* the size epsilon is reused (:606) */
+    else t_split = (nd.cut - r.o[axis]) / r.d[axis];
+    int near_id = nd.left, far_id = nd.right;
+    if (!(r.d[axis] >= 0)) std::swap(near_id, far_id);
+    if (t_split <= t_in) return kd_node_hit(s, far_id, r, t_in, t_out, best, c);
+    else if (t_split >= t_out) return kd_node_hit(s, near_id, r, t_in, t_out, best, c);
+    else {
+        bool hn = kd_node_hit(s, near_id, r, t_in, t_split, best, c);
+        bool hf = false;
+        if (!hn || best.t > t_split) hf = kd_node_hit(s, far_id, r, t_split, t_out, best, c);
+        return hn || hf;
+    }
+}
+
+/* Scene::computeIntersection, R/src/Scene.h:169-205 via KDTree::intersect, KDTree.cpp:679-687. */
+Hit closest_hit(const OScene& s, const Ray& r, Counters& c) {
+    ++c.rays;
+    Hit h;
+    if (s.kd.empty()) return h;
+    float t_in, t_out;
+    if (!box_hit(s.kd[0].box, r, t_in, t_out, c)) return h;
+    if (!kd_node_hit(s, 0, r, t_in, t_out, h, c)) { h = Hit(); }
+    return h;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * Random numbers: glibc rand() (R/main.cpp:186-187, R/src/Scene.h:259-260) or the shared
+ * counter generator of include/rtamd.h.
+ * -------------------------------------------------------------------------------------- */
+struct Rng {
+    int mode = RT_RNG_COUNTER;
+    uint32_t key = 0, k = 0;
+    uint32_t next() {
+        if (mode == RT_RNG_LIBC) return (uint32_t)std::rand();
+        return rt_rand31(key, k++);
+    }
+    /* (float)rand() / RAND_MAX with RAND_MAX = 2147483647 converted to float = 2^31 */
+    float unit() { return static_cast<float>((int)next()) / 2147483648.f; }
+};
+
+/* ----------------------------------------------------------------------------------------
+ * Shading.
+ * -------------------------------------------------------------------------------------- */
+const rt_material& material_of(const OScene& s, const Hit& h) { /* Scene.h:283-301 */
+    int m = h.type == RT_SPHERE ? s.spheres[h.object].material
+          : h.type == RT_SQUARE ? s.squares[h.object].material
+                                : s.meshes[h.object].material;
+    return s.materials[m];
+}
+
+/* Scene::computeLightContribution, R/src/Scene.h:304-316. */
+void light_term(V3& sum, const rt_light& lt, const rt_material& mat, const V3& N, const V3& V, const V3& L) {
+    V3 R = sub(mul(2.f * dot(N, L), N), L); /* 2. * dot is exact in double, narrowed to float */
+    normalize(R);
+    for (int i = 0; i < 3; ++i) {
+        float Isd = lt.color[i];
+        sum[i] += Isd * mat.diffuse[i] * smax(0.f, dot(L, N));
+        sum[i] += Isd * mat.specular[i] * std::pow(smax(0.f, dot(R, V)), mat.shininess); /* powf */
+    }
+}
+
+/* Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276). */
+V3 phong(const OScene& s, const Hit& h, Rng& rng, Counters& c) {
+    ++c.nodes;
+    float Ka = 0.35f;
+    V3 ambient = mul(Ka, V3(0.2f, 0.2f, 0.2f)); /* globalAmbientLight, Scene.h:24 */
+    V3 diffuse, specular;
+    const rt_material& mat = material_of(s, h);
+    for (const rt_light& lt : s.lights) {
+        V3 P = h.p, N = h.n;
+        normalize(N);
+        if (lt.type == RT_LIGHT_QUAD) {
+            V3 sum;
+            const int n_samples = 16;
+            V3 p0 = from3(lt.p0), p1 = from3(lt.p1), p2 = from3(lt.p2);
+            for (int i = 0; i < n_samples; ++i) {
+                ++c.light_samples;
+                float u = rng.unit();
+                float v = rng.unit();
+                if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+                V3 S = add(add(mul(1 - u - v, p0), mul(u, p1)), mul(v, p2));
+                V3 L = sub(S, P);
+                normalize(L);
+                V3 V = mul(-1.f, P);
+                normalize(V);
+                Ray shadow(add(P, mul(0.001f, N)), L); /* (float)0.001 */
+                Hit sh = closest_hit(s, shadow, c);
+                if (sh.hit && sh.t < length(sub(S, P))) continue;
+                light_term(sum, lt, mat, N, V, L);
+            }
+            sum = divs(sum, 16.f);
+            diffuse = add(diffuse, sum);
+            specular = add(specular, sum); /* counted twice, as the reference does (:393-394) */
+        } else {
+            V3 lp = from3(lt.pos);
+            V3 L = sub(lp, P);
+            normalize(L);
+            V3 V = mul(-1.f, P);
+            normalize(V);
+            Ray shadow(add(P, mul(0.001f, N)), L);
+            Hit sh = closest_hit(s, shadow, c);
+            if (sh.hit && sh.t < length(sub(lp, P))) continue;
+            light_term(diffuse, lt, mat, N, V, L);
+        }
+    }
+    return add(add(ambient, diffuse), specular);
+}
+
+/* Scene::rayTraceRecursive, R/src/Scene.h:596-713. */
+V3 trace(const OScene& s, const Ray& ray, int bounces, Rng& rng, Counters& c) {
+    Hit h = closest_hit(s, ray, c);
+    if (!h.hit) return V3();
+    V3 color = phong(s, h, rng, c);
+    if (bounces > 0 && h.type == RT_SPHERE) {
+        const rt_material& mat = material_of(s, h);
+        V3 P = h.p, N = h.n, I = ray.d;
+        if (mat.type == RT_MAT_MIRROR) {
+            V3 R = sub(I, mul(2.0f * dot(I, N), N));
+            Ray refl(add(P, mul(0.001f, N)), R);
+            V3 rc = trace(s, refl, bounces - 1, rng, c);
+            for (int i = 0; i < 3; ++i) color[i] += rc[i] * mat.specular[i];
+        }
+        if (mat.type == RT_MAT_GLASS) {
+            float n1 = 1.0f, n2 = mat.index_medium;
+            if (dot(I, N) > 0.0f) { std::swap(n1, n2); N = mul(-1.0f, N); }
+            float cosI = std::fabs(dot(I, N));
+            float sinT2 = (n1 / n2) * (n1 / n2) * (1.0f - cosI * cosI);
+            float F;
+            if (sinT2 > 1.0f) F = 1.0f;
+            else {
+                float cosT = std::sqrt(1.0f - sinT2);
+                /* pow(x, 2) runs in double: the exact square, rounded once to float */
+                float rs = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+                float rp = (n1 * cosT - n2 * cosI) / (n1 * cosT + n2 * cosI);
+                float Rs = (float)((double)rs * (double)rs);
+                float Rp = (float)((double)rp * (double)rp);
+                F = (Rs + Rp) / 2.0f;
+            }
+            V3 R = sub(I, mul(2.0f * dot(I, N), N));
+            Ray refl(add(P, mul(0.001f, N)), R);
+            V3 rc = trace(s, refl, bounces - 1, rng, c);
+            V3 tc;
+            if (F < 1.0f) {
+                V3 T = sub(mul(n1 / n2, sub(I, mul(cosI, N))), mul(std::sqrt(1.0f - sinT2), N));
+                Ray refr(sub(P, mul(0.001f, N)), T);
+                tc = trace(s, refr, bounces - 1, rng, c);
+            }
+            color = add(mul(F, rc), mul(1.0f - F, tc));
+        }
+    }
+    return color;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * Camera.  R/src/Camera.cpp:24-50,125-132 set the OpenGL PROJECTION / MODELVIEW state and
+ * R/src/matrixUtilities.h:188-222 reads it back as double and inverts it for every sample.
+ * -------------------------------------------------------------------------------------- */
+
+/* 4x4 inverse by cofactors, term order of the classic GLU routine the reference carries
+ * (R/src/matrixUtilities.h:6-135).  Row o of the table lists, for output element o, six signed
+ * products m[i]*m[j]*m[k] in evaluation order. */
+struct Term { int sign, i, j, k; };
+const Term COF[16][6] = {
+    /* 0*/ {{+1, 5, 10, 15}, {-1, 5, 11, 14}, {-1, 9, 6, 15}, {+1, 9, 7, 14}, {+1, 13, 6, 11}, {-1, 13, 7, 10}},
+    /* 1*/ {{-1, 1, 10, 15}, {+1, 1, 11, 14}, {+1, 9, 2, 15}, {-1, 9, 3, 14}, {-1, 13, 2, 11}, {+1, 13, 3, 10}},
+    /* 2*/ {{+1, 1, 6, 15}, {-1, 1, 7, 14}, {-1, 5, 2, 15}, {+1, 5, 3, 14}, {+1, 13, 2, 7}, {-1, 13, 3, 6}},
+    /* 3*/ {{-1, 1, 6, 11}, {+1, 1, 7, 10}, {+1, 5, 2, 11}, {-1, 5, 3, 10}, {-1, 9, 2, 7}, {+1, 9, 3, 6}},
+    /* 4*/ {{-1, 4, 10, 15}, {+1, 4, 11, 14}, {+1, 8, 6, 15}, {-1, 8, 7, 14}, {-1, 12, 6, 11}, {+1, 12, 7, 10}},
+    /* 5*/ {{+1, 0, 10, 15}, {-1, 0, 11, 14}, {-1, 8, 2, 15}, {+1, 8, 3, 14}, {+1, 12, 2, 11}, {-1, 12, 3, 10}},
+    /* 6*/ {{-1, 0, 6, 15}, {+1, 0, 7, 14}, {+1, 4, 2, 15}, {-1, 4, 3, 14}, {-1, 12, 2, 7}, {+1, 12, 3, 6}},
+    /* 7*/ {{+1, 0, 6, 11}, {-1, 0, 7, 10}, {-1, 4, 2, 11}, {+1, 4, 3, 10}, {+1, 8, 2, 7}, {-1, 8, 3, 6}},
+    /* 8*/ {{+1, 4, 9, 15}, {-1, 4, 11, 13}, {-1, 8, 5, 15}, {+1, 8, 7, 13}, {+1, 12, 5, 11}, {-1, 12, 7, 9}},
+    /* 9*/ {{-1, 0, 9, 15}, {+1, 0, 11, 13}, {+1, 8, 1, 15}, {-1, 8, 3, 13}, {-1, 12, 1, 11}, {+1, 12, 3, 9}},
+    /*10*/ {{+1, 0, 5, 15}, {-1, 0, 7, 13}, {-1, 4, 1, 15}, {+1, 4, 3, 13}, {+1, 12, 1, 7}, {-1, 12, 3, 5}},
+    /*11*/ {{-1, 0, 5, 11}, {+1, 0, 7, 9}, {+1, 4, 1, 11}, {-1, 4, 3, 9}, {-1, 8, 1, 7}, {+1, 8, 3, 5}},
+    /*12*/ {{-1, 4, 9, 14}, {+1, 4, 10, 13}, {+1, 8, 5, 14}, {-1, 8, 6, 13}, {-1, 12, 5, 10}, {+1, 12, 6, 9}},
+    /*13*/ {{+1, 0, 9, 14}, {-1, 0, 10, 13}, {-1, 8, 1, 14}, {+1, 8, 2, 13}, {+1, 12, 1, 10}, {-1, 12, 2, 9}},
+    /*14*/ {{-1, 0, 5, 14}, {+1, 0, 6, 13}, {+1, 4, 1, 14}, {-1, 4, 2, 13}, {-1, 12, 1, 6}, {+1, 12, 2, 5}},
+    /*15*/ {{+1, 0, 5, 10}, {-1, 0, 6, 9}, {-1, 4, 1, 10}, {+1, 4, 2, 9}, {+1, 8, 1, 6}, {-1, 8, 2, 5}},
+};
+bool invert4(const double m[16], double out[16]) {
+    double inv[16];
+    for (int o = 0; o < 16; ++o) {
+        double acc = 0.0;
+        for (int t = 0; t < 6; ++t) {
+            const Term& T = COF[o][t];
+            double prod = m[T.i] * m[T.j] * m[T.k];
+            /* the reference negates the first factor of a leading negative term and subtracts
+             * the others; both equal adding the negated product */
+            if (t == 0) acc = (T.sign > 0) ? prod : -prod;
+            else acc = (T.sign > 0) ? acc + prod : acc - prod;
+        }
+        inv[o] = acc;
+    }
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * det;
+    return true;
+}
+
+/* mult(), column-major: R/src/matrixUtilities.h:164-170. */
+inline void mat_vec(const double m[16], double x, double y, double z, double w, double r[4]) {
+    r[0] = m[0] * x + m[4] * y + m[8] * z + m[12] * w;
+    r[1] = m[1] * x + m[5] * y + m[9] * z + m[13] * w;
+    r[2] = m[2] * x + m[6] * y + m[10] * z + m[14] * w;
+    r[3] = m[3] * x + m[7] * y + m[11] * z + m[15] * w;
+}
+
+struct CamInv {
+    double proj_inv[16], mv_inv[16], depth_near;
+    V3 eye; /* cameraSpaceToWorldSpace(0,0,0), :188-197 */
+};
+CamInv invert_camera(const rt_camera& cam) {
+    CamInv ci;
+    double p[16], mv[16];
+    for (int i = 0; i < 16; ++i) { p[i] = cam.projection[i]; mv[i] = cam.modelview[i]; }
+    invert4(p, ci.proj_inv);
+    invert4(mv, ci.mv_inv);
+    ci.depth_near = cam.depth_near;
+    double r[4];
+    mat_vec(ci.mv_inv, 0.0, 0.0, 0.0, 1.0, r);
+    ci.eye = V3((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]));
+    return ci;
+}
+/* screen_space_to_world_space_ray, :198-222.  Returns the direction normalised once. */
+inline void primary_ray(const CamInv& ci, float u, float v, V3& o, V3& d) {
+    double a[4], b[4];
+    mat_vec(ci.proj_inv, (double)2.f * u - 1.f, -((double)2.f * v - 1.f), ci.depth_near, 1.0, a);
+    mat_vec(ci.mv_inv, a[0], a[1], a[2], a[3], b);
+    V3 w((float)(b[0] / b[3]), (float)(b[1] / b[3]), (float)(b[2] / b[3]));
+    o = ci.eye;
+    d = sub(w, o);
+    normalize(d);
+}
+
+/* OpenGL state the reference builds.  gluPerspective (SGI libGLU, project.c): double math,
+ * stored by the GL as float.  Modelview: glLoadIdentity, glTranslatef(x,y,z),
+ * glTranslatef(0,0,-zoom), glMultMatrixf(rotation) with Mesa's float matrix arithmetic;
+ * rotation = build_rotmatrix(quaternion), R/src/Trackball.cpp:323-345 (double expressions
+ * narrowed to float).  Only the identity-rotation case is pinned by the known-answer render. */
+void camera_matrices(double fovy, float aspect, double z_near, double z_far, float x, float y, float z,
+                     float zoom, const float q[4], rt_camera& cam) {
+    const double pi = 3.14159265358979323846;
+    double radians = fovy / 2 * pi / 180;
+    double dz = z_far - z_near, sine = std::sin(radians), cot = std::cos(radians) / sine;
+    double P[16] = {0};
+    P[0] = cot / (double)aspect; P[5] = cot; P[10] = -(z_far + z_near) / dz; P[11] = -1;
+    P[14] = -2 * z_near * z_far / dz; P[15] = 0;
+    for (int i = 0; i < 16; ++i) cam.projection[i] = (float)P[i];
+    float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    auto translate = [&](float tx, float ty, float tz) {
+        m[12] = m[0] * tx + m[4] * ty + m[8] * tz + m[12];
+        m[13] = m[1] * tx + m[5] * ty + m[9] * tz + m[13];
+        m[14] = m[2] * tx + m[6] * ty + m[10] * tz + m[14];
+        m[15] = m[3] * tx + m[7] * ty + m[11] * tz + m[15];
+    };
+    translate(x, y, z);
+    translate(0.f, 0.f, -zoom);
+    float r[16];
+    r[0] = (float)(1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]));
+    r[1] = (float)(2.0 * (q[0] * q[1] - q[2] * q[3]));
+    r[2] = (float)(2.0 * (q[2] * q[0] + q[1] * q[3]));
+    r[3] = 0.f;
+    r[4] = (float)(2.0 * (q[0] * q[1] + q[2] * q[3]));
+    r[5] = (float)(1.0 - 2.0 * (q[2] * q[2] + q[0] * q[0]));
+    r[6] = (float)(2.0 * (q[1] * q[2] - q[0] * q[3]));
+    r[7] = 0.f;
+    r[8] = (float)(2.0 * (q[2] * q[0] - q[1] * q[3]));
+    r[9] = (float)(2.0 * (q[1] * q[2] + q[0] * q[3]));
+    r[10] = (float)(1.0 - 2.0 * (q[1] * q[1] + q[0] * q[0]));
+    r[11] = 0.f;
+    r[12] = r[13] = r[14] = 0.f; r[15] = 1.f;
+    float out[16];
+    for (int c = 0; c < 4; ++c)
+        for (int rr = 0; rr < 4; ++rr)
+            out[c * 4 + rr] = m[rr] * r[c * 4] + m[4 + rr] * r[c * 4 + 1] + m[8 + rr] * r[c * 4 + 2] +
+                              m[12 + rr] * r[c * 4 + 3];
+    for (int i = 0; i < 16; ++i) cam.modelview[i] = out[i];
+    cam.depth_near = 0.f;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * Built-in scenes: R/src/Scene.h:722-1048, with the Square / Mesh transforms they call.
+ * -------------------------------------------------------------------------------------- */
+struct Quad { V3 p[4]; };
+
+/* Square::setQuad, R/src/Square.h:30-61 (positions only). */
+Quad quad_set(V3 bl, V3 right, V3 up, float width, float height) {
+    normalize(right); normalize(up);
+    right = mul(width, right); up = mul(height, up);
+    Quad q;
+    q.p[0] = bl;
+    q.p[1] = add(bl, right);
+    q.p[2] = add(add(bl, right), up);
+    q.p[3] = add(bl, up);
+    return q;
+}
+/* Mat3 * Vec3, R/src/Vec3.h:156-163, applied to every vertex (Mesh.h:134-137). */
+void quad_apply(Quad& q, const float M[9]) {
+    for (V3& p : q.p)
+        p = V3(M[0] * p[0] + M[1] * p[1] + M[2] * p[2], M[3] * p[0] + M[4] * p[1] + M[5] * p[2],
+               M[6] * p[0] + M[7] * p[1] + M[8] * p[2]);
+}
+void quad_scale(Quad& q, float sx, float sy, float sz) { /* Mesh.h:144-149 */
+    float M[9] = {sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz};
+    quad_apply(q, M);
+}
+void quad_translate(Quad& q, const V3& t) { for (V3& p : q.p) p = add(p, t); } /* Mesh.h:128-132 */
+/* rotate_x / rotate_y, Mesh.h:151-165: the angle is narrowed to float, cos / sin are taken in
+ * double on that float and narrowed again by the Mat3 constructor.  (For the four angles the
+ * built-in scenes use, cosf / sinf give the same bits; orc_selfcheck() verifies that.) */
+float rad_of(float deg) { return (float)(deg * 3.14159265358979323846 / 180.); }
+void quad_rot_x(Quad& q, float deg) {
+    float a = rad_of(deg);
+    float c = (float)std::cos((double)a), s = (float)std::sin((double)a);
+    float M[9] = {1.f, 0.f, 0.f, 0.f, c, -s, 0.f, s, c};
+    quad_apply(q, M);
+}
+void quad_rot_y(Quad& q, float deg) {
+    float a = rad_of(deg);
+    float c = (float)std::cos((double)a), s = (float)std::sin((double)a);
+    float M[9] = {c, 0.f, s, 0.f, 1.f, 0.f, -s, 0.f, c};
+    quad_apply(q, M);
+}
+
+int add_material(OScene& s, V3 kd, V3 ks, double shininess, float ior, int type) {
+    rt_material m;
+    for (int i = 0; i < 3; ++i) { m.diffuse[i] = kd[i]; m.specular[i] = ks[i]; }
+    m.shininess = (float)shininess; m.index_medium = ior; m.type = type;
+    s.materials.push_back(m);
+    return (int)s.materials.size() - 1;
+}
+void add_square(OScene& s, const Quad& q, int mat) {
+    rt_square sq;
+    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) sq.v[i][a] = q.p[i][a];
+    sq.material = mat;
+    s.squares.push_back(sq);
+}
+void add_sphere(OScene& s, V3 c, float r, int mat) {
+    rt_sphere sp; sp.center[0] = c[0]; sp.center[1] = c[1]; sp.center[2] = c[2];
+    sp.radius = r; sp.material = mat;
+    s.spheres.push_back(sp);
+}
+void add_point_light(OScene& s) { /* Scene.h:728-737 */
+    rt_light l{};
+    l.type = RT_LIGHT_SPHERICAL;
+    l.pos[0] = -5; l.pos[1] = 5; l.pos[2] = 5;
+    l.color[0] = l.color[1] = l.color[2] = 1;
+    s.lights.push_back(l);
+}
+void add_quad_light(OScene& s) { /* Scene.h:816-826 + initialize_quad_light :49-69 */
+    rt_light l{};
+    l.type = RT_LIGHT_QUAD;
+    V3 pos(0.f, 1.5f, 0.f);
+    float hw = 4.0f * 0.5f, hh = 4.0f * 0.5f;
+    V3 a = add(pos, V3(-hw, -hh, 0)), b = add(pos, V3(hw, -hh, 0)), c = add(pos, V3(hw, hh, 0));
+    for (int i = 0; i < 3; ++i) { l.pos[i] = pos[i]; l.color[i] = 1.f; l.p0[i] = a[i]; l.p1[i] = b[i]; l.p2[i] = c[i]; }
+    s.lights.push_back(l);
+}
+Quad unit_wall() { return quad_set(V3(-1.f, -1.f, 0.f), V3(1.f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f); }
+
+/* The five Cornell walls, Scene.h:828-891 == :951-1014. */
+void add_cornell_walls(OScene& s) {
+    V3 back(0.f, 0.f, -2.f);
+    { Quad q = unit_wall(); quad_scale(q, 2.f, 2.f, 1.f); quad_translate(q, back);
+      add_square(s, q, add_material(s, V3(1.f, 0.5f, 0.f), V3(1.f, 1.f, 1.f), 16, 1.f, RT_MAT_DIFFUSE)); }
+    { Quad q = unit_wall(); quad_scale(q, 2.f, 2.f, 1.f); quad_translate(q, back); quad_rot_y(q, 90);
+      add_square(s, q, add_material(s, V3(1.f, 0.f, 0.f), V3(1.f, 0.f, 0.f), 16, 1.f, RT_MAT_DIFFUSE)); }
+    { Quad q = unit_wall(); quad_translate(q, back); quad_scale(q, 2.f, 2.f, 1.f); quad_rot_y(q, -90);
+      add_square(s, q, add_material(s, V3(0.f, 1.f, 0.f), V3(0.f, 1.f, 0.f), 16, 1.f, RT_MAT_DIFFUSE)); }
+    { Quad q = unit_wall(); quad_translate(q, back); quad_scale(q, 2.f, 2.f, 1.f); quad_rot_x(q, -90);
+      add_square(s, q, add_material(s, V3(0.5f, 0.5f, 1.f), V3(1.f, 1.f, 1.f), 16, 1.f, RT_MAT_DIFFUSE)); }
+    { Quad q = unit_wall(); quad_translate(q, back); quad_scale(q, 2.f, 2.f, 1.f); quad_rot_x(q, 90);
+      add_square(s, q, add_material(s, V3(0.f, 0.f, 1.f), V3(1.f, 1.f, 1.f), 16, 1.f, RT_MAT_DIFFUSE)); }
+}
+
+/* Mesh::loadOFF + centerAndScaleToUnit + recomputeNormals, R/src/Mesh.cpp:21-69. */
+bool load_off(const char* path, std::vector<V3>& pos, std::vector<uint32_t>& tri) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) return false;
+    char tag[64];
+    unsigned nv = 0, nt = 0, ne = 0;
+    if (std::fscanf(f, "%63s %u %u %u", tag, &nv, &nt, &ne) != 4) { std::fclose(f); return false; }
+    pos.resize(nv); tri.resize(3 * (size_t)nt);
+    for (unsigned i = 0; i < nv; ++i)
+        if (std::fscanf(f, "%f %f %f", &pos[i][0], &pos[i][1], &pos[i][2]) != 3) { std::fclose(f); return false; }
+    for (unsigned i = 0; i < nt; ++i) {
+        int k;
+        if (std::fscanf(f, "%d %u %u %u", &k, &tri[3 * i], &tri[3 * i + 1], &tri[3 * i + 2]) != 4) { std::fclose(f); return false; }
+    }
+    std::fclose(f);
+    return true;
+}
+void center_and_scale(std::vector<V3>& pos) {
+    V3 c;
+    for (const V3& p : pos) c = add(c, p);
+    c = divs(c, (float)pos.size());
+    float maxd = length(sub(pos[0], c));
+    for (const V3& p : pos) { float m = length(sub(p, c)); if (m > maxd) maxd = m; }
+    for (V3& p : pos) p = divs(sub(p, c), maxd);
+}
+void recompute_normals(const std::vector<V3>& pos, const std::vector<uint32_t>& tri, std::vector<V3>& nrm) {
+    nrm.assign(pos.size(), V3());
+    for (size_t i = 0; i < tri.size() / 3; ++i) {
+        V3 e01 = sub(pos[tri[3 * i + 1]], pos[tri[3 * i]]), e02 = sub(pos[tri[3 * i + 2]], pos[tri[3 * i]]);
+        V3 n = cross(e01, e02);
+        normalize(n);
+        for (int j = 0; j < 3; ++j) nrm[tri[3 * i + j]] = add(nrm[tri[3 * i + j]], n);
+    }
+    for (V3& n : nrm) normalize(n);
+}
+
+bool build_builtin(OScene& s, int id, const char* off_path) {
+    if (id == 0) { /* setup_single_sphere, Scene.h:722-765 */
+        add_point_light(s);
+        add_sphere(s, V3(1.f, 0.f, 0.f), 1.f, add_material(s, V3(1.f, 0.f, 0.f), V3(0.2f, 0.2f, 0.2f), 20, 1.f, RT_MAT_MIRROR));
+        add_sphere(s, V3(0.f, 0.f, 1.f), 1.f, add_material(s, V3(0.f, 1.f, 0.f), V3(0.2f, 0.2f, 0.2f), 20, 1.f, RT_MAT_MIRROR));
+    } else if (id == 1) { /* setup_single_square, Scene.h:767-807 */
+        add_point_light(s);
+        add_square(s, quad_set(V3(-1.f, -1.f, 0.f), V3(1.f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f),
+                   add_material(s, V3(1.f, 0.f, 0.f), V3(0.8f, 0.8f, 0.8f), 20, 1.f, RT_MAT_DIFFUSE));
+        add_square(s, quad_set(V3(-1.5f, -1.f, 0.f), V3(0.5f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f),
+                   add_material(s, V3(0.f, 1.f, 0.f), V3(0.8f, 0.8f, 0.8f), 20, 1.f, RT_MAT_DIFFUSE));
+    } else if (id == 2) { /* setup_cornell_box, Scene.h:932-1048 */
+        add_quad_light(s);
+        add_cornell_walls(s);
+        add_sphere(s, V3(1.0f, -1.25f, 0.5f), 0.75f, add_material(s, V3(1.f, 1.f, 1.f), V3(1.f, 1.f, 1.f), 16, 1.4f, RT_MAT_MIRROR));
+        add_sphere(s, V3(-1.0f, -1.25f, -0.5f), 0.75f, add_material(s, V3(1.f, 1.f, 1.f), V3(1.f, 1.f, 1.f), 16, 1.5f, RT_MAT_GLASS));
+    } else if (id == 3) { /* setup_cornell_box_meshes, Scene.h:809-930 */
+        add_quad_light(s);
+        add_cornell_walls(s);
+        std::vector<V3> pos, nrm;
+        std::vector<uint32_t> tri;
+        if (!off_path || !load_off(off_path, pos, tri)) return false;
+        center_and_scale(pos);
+        recompute_normals(pos, tri, nrm);
+        float min_y = std::numeric_limits<float>::max();
+        for (const V3& p : pos) if (p[1] < min_y) min_y = p[1];
+        V3 shift(0.0f, (float)(-min_y - 1.8), 0.0f); /* -minY - 1.8 evaluated in double (:919) */
+        for (V3& p : pos) p = add(p, shift);
+        rt_mesh m{};
+        m.first_vertex = 0; m.n_vertices = (uint32_t)pos.size();
+        m.first_triangle = 0; m.n_triangles = (uint32_t)(tri.size() / 3);
+        /* default Material: black, shininess 0 (value-initialised by vector::resize) */
+        m.material = add_material(s, V3(), V3(), 0.0, 1.f, RT_MAT_DIFFUSE);
+        for (int a = 0; a < 3; ++a) { m.aabb_min[a] = INF; m.aabb_max[a] = -INF; } /* computeAABB never ran */
+        s.meshes.push_back(m);
+        for (const V3& p : pos) for (int a = 0; a < 3; ++a) s.positions.push_back(p[a]);
+        for (const V3& n : nrm) for (int a = 0; a < 3; ++a) s.normals.push_back(n[a]);
+        s.triangles = tri;
+    } else return false;
+    s.refresh_desc();
+    kd_build_scene(s);
+    return true;
+}
+
+void fill_hit(rt_hit& o, const Hit& h) {
+    o.hit = h.hit ? 1 : 0;
+    o.type = h.hit ? h.type : -1;
+    o.object = h.hit ? h.object : -1;
+    o.tri = (h.hit && h.type == RT_MESH) ? h.tri : -1;
+    o.t = h.hit ? h.t : FLT_MAX; /* RaySceneIntersection() : t(FLT_MAX), Scene.h:80 */
+    for (int a = 0; a < 3; ++a) { o.p[a] = h.hit ? h.p[a] : 0.f; o.n[a] = h.hit ? h.n[a] : 0.f; }
+    o.pad_ = 0.f;
+}
+
+} // namespace
+
+/* ========================================================================================
+ * C interface for the tests (ctypes).
+ * ====================================================================================== */
+extern "C" {
+
+struct orc_scene { OScene s; Counters total; };
+
+orc_scene* orc_scene_builtin(int id, const char* off_path) {
+    orc_scene* h = new orc_scene();
+    if (!build_builtin(h->s, id, off_path)) { delete h; return nullptr; }
+    return h;
+}
+
+orc_scene* orc_scene_from_desc(const rt_scene_desc* d) {
+    orc_scene* h = new orc_scene();
+    OScene& s = h->s;
+    s.spheres.assign(d->spheres, d->spheres + d->n_spheres);
+    s.squares.assign(d->squares, d->squares + d->n_squares);
+    s.meshes.assign(d->meshes, d->meshes + d->n_meshes);
+    s.lights.assign(d->lights, d->lights + d->n_lights);
+    s.materials.assign(d->materials, d->materials + d->n_materials);
+    s.positions.assign(d->positions, d->positions + 3 * (size_t)d->n_vertices);
+    s.normals.assign(d->normals, d->normals + 3 * (size_t)d->n_vertices);
+    s.triangles.assign(d->triangles, d->triangles + 3 * (size_t)d->n_triangles);
+    s.kd_max_depth = d->kd_max_depth; s.kd_max_leaf = d->kd_max_leaf; s.kd_epsilon = d->kd_epsilon;
+    s.refresh_desc();
+    kd_build_scene(s);
+    return h;
+}
+
+void orc_scene_free(orc_scene* h) { delete h; }
+
+const rt_scene_desc* orc_scene_desc(orc_scene* h) { return &h->s.desc; }
+
+/* Mesh::computeAABB for every mesh (R/src/Mesh.cpp:5-19, called from R/main.cpp:348-350 for the
+ * selected scene) followed by Scene::buildKDTree (main.cpp:353). */
+void orc_scene_compute_mesh_aabbs(orc_scene* h) {
+    OScene& s = h->s;
+    for (rt_mesh& m : s.meshes) {
+        for (int a = 0; a < 3; ++a) { m.aabb_min[a] = INF; m.aabb_max[a] = -INF; }
+        for (uint32_t i = 0; i < m.n_vertices; ++i)
+            for (int a = 0; a < 3; ++a) {
+                float v = s.positions[3 * (m.first_vertex + i) + a];
+                if (v < m.aabb_min[a]) m.aabb_min[a] = v;
+                if (v > m.aabb_max[a]) m.aabb_max[a] = v;
+            }
+    }
+    kd_build_scene(s);
+}
+
+/* same flattened layout as rt_scene_kdtree */
+void orc_scene_kdtree(orc_scene* h, int32_t* nodes, uint32_t* n_nodes, int32_t* refs, uint32_t* n_refs, float root_box[6]) {
+    const OScene& s = h->s;
+    uint32_t nr = 0;
+    for (size_t i = 0; i < s.kd.size(); ++i) {
+        const KdNode& k = s.kd[i];
+        if (nodes) {
+            int32_t* o = nodes + 8 * i;
+            o[0] = k.leaf; o[1] = k.axis; std::memcpy(&o[2], &k.cut, 4);
+            o[3] = k.left; o[4] = k.right; o[5] = (int32_t)nr; o[6] = (int32_t)k.refs.size(); o[7] = k.depth;
+        }
+        for (const Ref& r : k.refs) {
+            if (refs) { refs[2 * nr] = r.type; refs[2 * nr + 1] = r.object; }
+            ++nr;
+        }
+    }
+    if (n_nodes) *n_nodes = (uint32_t)s.kd.size();
+    if (n_refs) *n_refs = nr;
+    if (root_box && !s.kd.empty())
+        for (int a = 0; a < 3; ++a) { root_box[a] = s.kd[0].box.lo[a]; root_box[3 + a] = s.kd[0].box.hi[a]; }
+}
+
+/* Camera state of the default flow: Camera() (R/src/Camera.cpp:24-38), resize(w,h) (:41-50),
+ * camera.move(0,0,-3.1) (R/main.cpp:339), apply() (:125-132). */
+void orc_camera_default(uint32_t w, uint32_t h, rt_camera* cam) {
+    float fov = 45.0f, z_near = 4.1f, z_far = 10000.0f;
+    float aspect = static_cast<float>((int)w) / static_cast<float>((int)h);
+    float x = 0.f, y = 0.f, z = 0.f;
+    z += (float)-3.1;
+    float q[4] = {0.f, 0.f, 0.f, 1.f};
+    camera_matrices(fov, aspect, z_near, z_far, x, y, z, 3.0f, q, *cam);
+}
+void orc_camera_build(float fov, float z_near, float z_far, uint32_t w, uint32_t h, float x, float y, float z,
+                      float zoom, const float quat[4], rt_camera* cam) {
+    float aspect = static_cast<float>((int)w) / static_cast<float>((int)h);
+    camera_matrices(fov, aspect, z_near, z_far, x, y, z, zoom, quat, *cam);
+}
+
+void orc_generate_rays(const rt_camera* cam, const float* u, const float* v, size_t n, float* org, float* dir) {
+    CamInv ci = invert_camera(*cam);
+    for (size_t i = 0; i < n; ++i) {
+        V3 o, d;
+        primary_ray(ci, u[i], v[i], o, d);
+        for (int a = 0; a < 3; ++a) { org[3 * i + a] = o[a]; dir[3 * i + a] = d[a]; }
+    }
+}
+
+void orc_intersect(orc_scene* h, const float* org, const float* dir, size_t n, rt_hit* out) {
+    Counters c;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r(from3(org + 3 * i), from3(dir + 3 * i));
+        fill_hit(out[i], closest_hit(h->s, r, c));
+    }
+    h->total += c;
+}
+
+void orc_mesh_intersect(orc_scene* h, uint32_t mesh, const float* org, const float* dir, size_t n, rt_hit* out) {
+    Counters c;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r(from3(org + 3 * i), from3(dir + 3 * i));
+        Hit hit;
+        if (mesh_hit(h->s, h->s.meshes[mesh], r, hit, c)) { hit.type = RT_MESH; hit.object = (int)mesh; }
+        fill_hit(out[i], hit);
+    }
+}
+
+void orc_trace(orc_scene* h, const float* org, const float* dir, size_t n, const uint32_t* pixel, const uint32_t* sample,
+               uint32_t seed, uint32_t k0, float* rgb, rt_stats* stats) {
+    Counters c;
+    for (size_t i = 0; i < n; ++i) {
+        Rng rng;
+        rng.key = rt_rng_key(seed, pixel[i], sample[i]);
+        rng.k = k0;
+        Ray r(from3(org + 3 * i), from3(dir + 3 * i));
+        V3 col = trace(h->s, r, 10, rng, c); /* Scene::rayTrace, Scene.h:716-720 */
+        ++c.samples;
+        for (int a = 0; a < 3; ++a) rgb[3 * i + a] = col[a];
+    }
+    h->total += c;
+    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; }
+}
+
+/* ray_trace_from_camera, R/main.cpp:170-203, rows [y0, y1) of a w x h image.  rgb is the full
+ * row-major w*h*3 float image (only the requested rows are written).  RT_RNG_LIBC runs the
+ * rows in order on one thread after srand(1) -- the state glibc starts a process with;
+ * RT_RNG_COUNTER may use `threads` workers (rows are independent under the counter RNG). */
+void orc_render(orc_scene* h, const rt_camera* cam, uint32_t w, uint32_t hgt, uint32_t spp, int rng_mode,
+                uint32_t seed, uint32_t y0, uint32_t y1, int threads, float* rgb, rt_stats* stats) {
+    const OScene& s = h->s;
+    CamInv ci = invert_camera(*cam);
+    if (rng_mode == RT_RNG_LIBC) { std::srand(1); threads = 1; }
+    if (threads < 1) threads = 1;
+    std::vector<Counters> cs(threads);
+    std::atomic<uint32_t> next_row(y0);
+    auto work = [&](int tid) {
+        Counters& c = cs[tid];
+        for (;;) {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= y1) break;
+            for (uint32_t x = 0; x < w; ++x) {
+                V3 acc;
+                for (uint32_t sidx = 0; sidx < spp; ++sidx) {
+                    Rng rng;
+                    rng.mode = rng_mode;
+                    rng.key = rt_rng_key(seed, x + y * w, sidx);
+                    float u = ((float)(int)x + rng.unit()) / (int)w;
+                    float v = ((float)(int)y + rng.unit()) / (int)hgt;
+                    V3 o, d;
+                    primary_ray(ci, u, v, o, d);
+                    V3 col = trace(s, Ray(o, d), 10, rng, c);
+                    ++c.samples;
+                    acc = add(acc, col);
+                }
+                acc = divs(acc, (float)spp);
+                for (int a = 0; a < 3; ++a) rgb[3 * ((size_t)x + (size_t)y * w) + a] = acc[a];
+            }
+        }
+    };
+    if (threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto& t : pool) t.join();
+    }
+    Counters c;
+    for (const Counters& x : cs) c += x;
+    h->total += c;
+    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; }
+}
+
+/* PPM quantisation, R/main.cpp:213: (int)(255.f * min(1.f, c)). */
+void orc_quantize(const float* rgb, size_t n_values, uint8_t* out) {
+    for (size_t i = 0; i < n_values; ++i) out[i] = (uint8_t)(int)(255.f * smin(1.f, rgb[i]));
+}
+
+/* Accumulated event counters since the scene was created: fills 16 uint64 in the order of the
+ * Counters struct and returns the algorithmic FLOP total of include/rt_flops.h. */
+double orc_scene_counters(orc_scene* h, uint64_t out[16]) {
+    const Counters& c = h->total;
+    uint64_t v[16] = {c.rays, c.samples, c.nodes, c.aabb, c.sph_miss, c.sph_hit, c.sq_behind, c.sq_reject,
+                      c.sq_hit, c.tri_par, c.tri_u, c.tri_v, c.tri_full, c.tri_upd, c.leaf_refs, c.light_samples};
+    if (out) std::memcpy(out, v, sizeof(v));
+    return c.flops();
+}
+void orc_scene_counters_reset(orc_scene* h) { h->total = Counters(); }
+
+/* 0 when the libm variants the reference might bind for the wall rotations agree bit for bit
+ * (double cos/sin narrowed to float vs cosf/sinf) on the four angles the scenes use. */
+int orc_selfcheck(void) {
+    int bad = 0;
+    for (float deg : {90.f, -90.f}) {
+        float a = rad_of(deg);
+        float c1 = (float)std::cos((double)a), c2 = cosf(a), s1 = (float)std::sin((double)a), s2 = sinf(a);
+        if (std::memcmp(&c1, &c2, 4) || std::memcmp(&s1, &s2, 4)) ++bad;
+    }
+    return bad;
+}
+
+} // extern "C"
