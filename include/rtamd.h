@@ -144,16 +144,21 @@ typedef uint64_t rt_scene_t;
  * A sample is identified by (seed, pixel = x + y*w, sample index s); the k-th rand() call the
  * reference would make while tracing that sample returns rt_rand31(rt_rng_key(..), k), a value
  * in [0, 2^31) like rand().  Integer-only, so CPU and GPU agree bit for bit. */
-static inline uint32_t rt_mix32(uint32_t x) {
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__
+#else
+#define RT_HD
+#endif
+RT_HD static inline uint32_t rt_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU;
     x ^= x >> 15; x *= 0x846ca68bU;
     x ^= x >> 16;
     return x;
 }
-static inline uint32_t rt_rng_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+RT_HD static inline uint32_t rt_rng_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
     return rt_mix32(seed ^ rt_mix32(pixel ^ rt_mix32(sample + 0x9E3779B9U)));
 }
-static inline uint32_t rt_rand31(uint32_t key, uint32_t k) {
+RT_HD static inline uint32_t rt_rand31(uint32_t key, uint32_t k) {
     return rt_mix32(key + k * 0x9E3779B9U) >> 1;
 }
 

@@ -1,0 +1,541 @@
+/*
+ * rt_api.hip -- HIP kernels and the C-ABI entry points of include/rtamd.h.
+ *
+ * Kernels (all in rt_device.h terms, gfx950, 256-thread workgroups = 4 waves):
+ *   k_render         one WAVE per pixel, one lane per sample of a 64-sample chunk; each lane traces
+ *                    its whole path tree; the wave then adds its lanes' colours in sample order
+ *                    (the reference's float summation order, R/main.cpp:185-193) and lane 0
+ *                    stores the pixel.  Lanes of a wave share a pixel, so they follow almost the
+ *                    same path and the scalar-cached scene tables stay wave-uniform.
+ *   k_intersect      one lane per ray: Scene::computeIntersection.
+ *   k_mesh_intersect one lane per ray: Mesh::intersect of one mesh.
+ *   k_trace          one lane per ray: Scene::rayTrace under the counter RNG.
+ *   k_generate       one lane per (u,v): screen_space_to_world_space_ray.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rt_build.h"
+#include "rt_device.h"
+
+/* ======================================================================================== */
+/*                                         kernels                                          */
+/* ======================================================================================== */
+
+struct RenderParams {
+    uint32_t w, h, spp, seed;
+    uint32_t tile_w, tile_h, tiles_x, n_tiles;
+    uint32_t rank, world, n_local_tiles, pad;
+};
+
+/* sum of a per-lane counter over the wave, in every lane */
+RT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
+    if (!counters) return;
+    uint32_t rays = wave_sum(c.rays), nodes = wave_sum(c.nodes), smp = wave_sum(samples);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&counters[0], (unsigned long long)rays);
+        atomicAdd((unsigned long long*)&counters[1], (unsigned long long)smp);
+        atomicAdd((unsigned long long*)&counters[2], (unsigned long long)nodes);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_render(DeviceScene sc, DCamera cam, RenderParams rp, float* __restrict__ out,
+                                                uint64_t* __restrict__ counters) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
+    const uint32_t local_tile = wave / px_per_tile;
+    if (local_tile >= rp.n_local_tiles) return; /* whole wave leaves together */
+    const uint32_t in_tile = wave - local_tile * px_per_tile;
+    const uint32_t tile = rp.rank + local_tile * rp.world;
+    const uint32_t x = (tile % rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
+    const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
+    float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
+    if (x >= rp.w || y >= rp.h) {
+        if (lane == 0) { dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; }
+        return;
+    }
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
+    uint32_t my_samples = 0;
+    f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane */
+    for (uint32_t s0 = 0; s0 < rp.spp; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        f3 col = mk3(0.f, 0.f, 0.f);
+        if (s < rp.spp) {
+            Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.k = 0;
+            /* R/main.cpp:186-187 */
+            float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
+            float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
+            f3 o, d;
+            primary_ray(cam, u, v, o, d);
+            col = trace_path(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
+            ++my_samples;
+        }
+        /* image[x + y*w] += color, one sample after the other */
+        const uint32_t n = min(64u, rp.spp - s0);
+        for (uint32_t i = 0; i < n; ++i) {
+            acc.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.x), (int)i));
+            acc.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.y), (int)i));
+            acc.z += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.z), (int)i));
+        }
+    }
+    acc = acc / (float)rp.spp; /* image /= nsamples */
+    if (lane == 0) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; }
+    flush_counters(counters, cnt, my_samples);
+}
+
+__global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir,
+                                                   size_t n, rt_hit* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
+    FullHit h = finish_hit(sc, closest_rec(sc, o, d, cnt), o, d);
+    rt_hit r;
+    r.hit = h.hit ? 1 : 0;
+    r.type = h.hit ? h.type : -1;
+    r.object = h.hit ? h.obj : -1;
+    r.tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)sc.meshes[h.obj].first_tri) : -1;
+    r.t = h.hit ? h.t : 3.402823466e+38f;
+    r.p[0] = h.p.x; r.p[1] = h.p.y; r.p[2] = h.p.z;
+    r.n[0] = h.n.x; r.n[1] = h.n.y; r.n[2] = h.n.z;
+    r.pad_ = 0.f;
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t mesh, const float* __restrict__ org,
+                                                        const float* __restrict__ dir, size_t n, rt_hit* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
+    HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
+    const DMesh m = sc.meshes[mesh];
+    if (mesh_closest(sc, m, o, d, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
+    FullHit h = finish_hit(sc, rec, o, d);
+    rt_hit r;
+    r.hit = h.hit ? 1 : 0;
+    r.type = h.hit ? RT_MESH : -1;
+    r.object = h.hit ? (int)mesh : -1;
+    r.tri = h.hit ? (int)(h.tri - (int)m.first_tri) : -1;
+    r.t = h.hit ? h.t : 3.402823466e+38f;
+    r.p[0] = h.p.x; r.p[1] = h.p.y; r.p[2] = h.p.z;
+    r.n[0] = h.n.x; r.n[1] = h.n.y; r.n[2] = h.n.z;
+    r.pad_ = 0.f;
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
+                                               const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
+                                               uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
+    uint32_t smp = 0;
+    if (i < n) {
+        f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
+        Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
+        f3 c = trace_path(sc, o, d, rng, cnt);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+        smp = 1;
+    }
+    flush_counters(counters, cnt, smp);
+}
+
+__global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __restrict__ u, const float* __restrict__ v, size_t n,
+                                                  float* __restrict__ org, float* __restrict__ dir) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o, d;
+    primary_ray(cam, u[i], v[i], o, d);
+    org[3 * i] = o.x; org[3 * i + 1] = o.y; org[3 * i + 2] = o.z;
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+}
+
+/* ======================================================================================== */
+/*                                       host state                                         */
+/* ======================================================================================== */
+
+namespace {
+
+struct SceneRes {
+    rtb::Built host;
+    DeviceScene dev{};
+    std::vector<void*> allocs;
+};
+
+struct Lib {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<rt_scene_t, SceneRes*> scenes;
+    rt_scene_t next_handle = 1;
+    std::string error;
+};
+Lib g;
+
+int fail(int code, const std::string& msg) { g.error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+template <class T>
+int upload(SceneRes* r, const std::vector<T>& v, const T** dst) {
+    *dst = nullptr;
+    if (v.empty()) return RT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    r->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T*)p;
+    return RT_OK;
+}
+
+void release(SceneRes* r) {
+    for (void* p : r->allocs) (void)hipFree(p);
+    delete r;
+}
+
+SceneRes* find(rt_scene_t h) {
+    auto it = g.scenes.find(h);
+    return it == g.scenes.end() ? nullptr : it->second;
+}
+
+/* device temporaries of the host-pointer entry points */
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    int get(void** out, size_t bytes) {
+        *out = nullptr;
+        if (bytes == 0) bytes = 16;
+        HIP_TRY(hipMalloc(out, bytes));
+        ptrs.push_back(*out);
+        return RT_OK;
+    }
+};
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+int make_render_params(uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
+                       uint32_t world, RenderParams& rp) {
+    if (w == 0 || h == 0 || spp == 0 || tile_w == 0 || tile_h == 0 || world == 0 || rank >= world)
+        return fail(RT_E_INVALID, "rt_render: zero size or rank >= world");
+    if ((uint64_t)w * h > 0x7fffffffull) return fail(RT_E_LIMIT, "rt_render: more than 2^31 pixels");
+    rp.w = w; rp.h = h; rp.spp = spp; rp.seed = seed;
+    rp.tile_w = tile_w; rp.tile_h = tile_h;
+    rp.tiles_x = (w + tile_w - 1) / tile_w;
+    uint32_t tiles_y = (h + tile_h - 1) / tile_h;
+    rp.n_tiles = rp.tiles_x * tiles_y;
+    rp.rank = rank; rp.world = world;
+    rp.n_local_tiles = (uint32_t)rt_tiles_per_rank(w, h, tile_w, tile_h, rank, world);
+    rp.pad = 0;
+    uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
+    if (waves / 4 + 1 > 0x7fffffffull) return fail(RT_E_LIMIT, "rt_render: grid too large");
+    return RT_OK;
+}
+
+}  // namespace
+
+/* ======================================================================================== */
+/*                                        C-ABI                                             */
+/* ======================================================================================== */
+
+extern "C" {
+
+const char* rt_last_error(void) { return g.error.c_str(); }
+
+int rt_init(int device) {
+    if (g.ready) {
+        if (device == g.device) return RT_OK;
+        return fail(RT_E_INVALID, "rt_init: already initialised on another device; call rt_shutdown first");
+    }
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RT_E_INVALID, "rt_init: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g.ev0));
+    HIP_TRY(hipEventCreate(&g.ev1));
+    g.device = device;
+    g.ready = true;
+    return RT_OK;
+}
+
+int rt_shutdown(void) {
+    if (!g.ready) return RT_OK;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    for (auto& kv : g.scenes) release(kv.second);
+    g.scenes.clear();
+    (void)hipEventDestroy(g.ev0);
+    (void)hipEventDestroy(g.ev1);
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr; g.ev0 = g.ev1 = nullptr;
+    g.ready = false; g.device = -1;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_scene_create: call rt_init first");
+    if (!desc || !out) return fail(RT_E_INVALID, "rt_scene_create: null argument");
+    HIP_TRY(hipSetDevice(g.device));
+    SceneRes* r = new SceneRes();
+    std::string err;
+    if (!rtb::build_scene(*desc, r->host, err)) { delete r; return fail(RT_E_INVALID, err); }
+    int max_depth = 0;
+    for (const DKdNode& k : r->host.kd) max_depth = k.depth > max_depth ? k.depth : max_depth;
+    if (max_depth >= RT_KD_MAX_DEPTH) { delete r; return fail(RT_E_LIMIT, "rt_scene_create: kd-tree deeper than 15 levels"); }
+    DeviceScene& d = r->dev;
+    int rc;
+    if ((rc = upload(r, r->host.spheres, &d.spheres)) || (rc = upload(r, r->host.squares, &d.squares)) ||
+        (rc = upload(r, r->host.meshes, &d.meshes)) || (rc = upload(r, r->host.tris, &d.tris)) ||
+        (rc = upload(r, r->host.normals, &d.normals)) || (rc = upload(r, r->host.materials, &d.materials)) ||
+        (rc = upload(r, r->host.lights, &d.lights)) || (rc = upload(r, r->host.kd, &d.kd)) ||
+        (rc = upload(r, r->host.refs, &d.refs))) {
+        release(r);
+        return rc;
+    }
+    d.n_spheres = (uint32_t)r->host.spheres.size(); d.n_squares = (uint32_t)r->host.squares.size();
+    d.n_meshes = (uint32_t)r->host.meshes.size(); d.n_lights = (uint32_t)r->host.lights.size();
+    d.n_kd = (uint32_t)r->host.kd.size(); d.n_refs = (uint32_t)r->host.refs.size();
+    for (int a = 0; a < 3; ++a) { d.box_lo[a] = r->host.box_lo[a]; d.box_hi[a] = r->host.box_hi[a]; }
+    d.kd_epsilon = r->host.kd_epsilon;
+    d.root_is_leaf = (!r->host.kd.empty() && r->host.kd[0].leaf) ? 1 : 0;
+    rt_scene_t h = g.next_handle++;
+    g.scenes[h] = r;
+    *out = h;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene_t scene) {
+    auto it = g.scenes.find(scene);
+    if (it == g.scenes.end()) return fail(RT_E_HANDLE, "rt_scene_destroy: unknown scene");
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    release(it->second);
+    g.scenes.erase(it);
+    return RT_OK;
+}
+
+int rt_scene_kdtree(rt_scene_t scene, int32_t* nodes, uint32_t* n_nodes, int32_t* refs, uint32_t* n_refs, float root_box[6]) {
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_scene_kdtree: unknown scene");
+    const rtb::Built& b = r->host;
+    if (nodes)
+        for (size_t i = 0; i < b.kd.size(); ++i) {
+            const DKdNode& k = b.kd[i];
+            int32_t* o = nodes + 8 * i;
+            o[0] = k.leaf; o[1] = k.axis; std::memcpy(&o[2], &k.cut, 4); o[3] = k.left; o[4] = k.right;
+            o[5] = k.leaf ? k.first_ref : 0; o[6] = k.leaf ? k.n_refs : 0; o[7] = k.depth;
+        }
+    if (refs) {
+        /* refs of the leaves in node order: leaf slices are already contiguous and ordered */
+        size_t w = 0;
+        for (const DKdNode& k : b.kd)
+            if (k.leaf)
+                for (int i = 0; i < k.n_refs; ++i) { refs[2 * w] = b.refs[k.first_ref + i].type; refs[2 * w + 1] = b.refs[k.first_ref + i].object; ++w; }
+    }
+    if (n_nodes) *n_nodes = (uint32_t)b.kd.size();
+    if (n_refs) *n_refs = (uint32_t)b.refs.size();
+    if (root_box) for (int a = 0; a < 3; ++a) { root_box[a] = b.box_lo[a]; root_box[3 + a] = b.box_hi[a]; }
+    return RT_OK;
+}
+
+int rt_intersect_device(rt_scene_t scene, const float* d_org, const float* d_dir, size_t n, rt_hit* d_out, void* hip_stream) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_intersect: call rt_init first");
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_intersect: unknown scene");
+    if (n == 0) return RT_OK;
+    if (!d_org || !d_dir || !d_out) return fail(RT_E_INVALID, "rt_intersect: null buffer");
+    if (n > 0x7fffffffull * 256) return fail(RT_E_LIMIT, "rt_intersect: too many rays for one launch");
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
+    hipLaunchKernelGGL(k_intersect, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_intersect(rt_scene_t scene, const float* org, const float* dir, size_t n, rt_hit* out) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_intersect: call rt_init first");
+    if (n == 0) return RT_OK;
+    if (!org || !dir || !out) return fail(RT_E_INVALID, "rt_intersect: null buffer");
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void *d_o, *d_d, *d_h;
+    int rc;
+    if ((rc = tmp.get(&d_o, 12 * n)) || (rc = tmp.get(&d_d, 12 * n)) || (rc = tmp.get(&d_h, sizeof(rt_hit) * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_o, org, 12 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_d, dir, 12 * n, hipMemcpyHostToDevice, g.stream));
+    if ((rc = rt_intersect_device(scene, (const float*)d_o, (const float*)d_d, n, (rt_hit*)d_h, g.stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_h, sizeof(rt_hit) * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RT_OK;
+}
+
+int rt_mesh_intersect(rt_scene_t scene, uint32_t mesh, const float* org, const float* dir, size_t n, rt_hit* out) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_mesh_intersect: call rt_init first");
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_mesh_intersect: unknown scene");
+    if (mesh >= r->dev.n_meshes) return fail(RT_E_INVALID, "rt_mesh_intersect: no such mesh");
+    if (n == 0) return RT_OK;
+    if (!org || !dir || !out) return fail(RT_E_INVALID, "rt_mesh_intersect: null buffer");
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void *d_o, *d_d, *d_h;
+    int rc;
+    if ((rc = tmp.get(&d_o, 12 * n)) || (rc = tmp.get(&d_d, 12 * n)) || (rc = tmp.get(&d_h, sizeof(rt_hit) * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_o, org, 12 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_d, dir, 12 * n, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_mesh_intersect, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, mesh, (const float*)d_o,
+                       (const float*)d_d, n, (rt_hit*)d_h);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_h, sizeof(rt_hit) * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RT_OK;
+}
+
+int rt_generate_rays(const rt_camera* cam, const float* u, const float* v, size_t n, float* org, float* dir) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_generate_rays: call rt_init first");
+    if (!cam) return fail(RT_E_INVALID, "rt_generate_rays: null camera");
+    if (n == 0) return RT_OK;
+    if (!u || !v || !org || !dir) return fail(RT_E_INVALID, "rt_generate_rays: null buffer");
+    DCamera dc;
+    std::string err;
+    if (!rtb::invert_camera(*cam, dc, err)) return fail(RT_E_INVALID, err);
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void *d_u, *d_v, *d_o, *d_d;
+    int rc;
+    if ((rc = tmp.get(&d_u, 4 * n)) || (rc = tmp.get(&d_v, 4 * n)) || (rc = tmp.get(&d_o, 12 * n)) || (rc = tmp.get(&d_d, 12 * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_u, u, 4 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_v, v, 4 * n, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n)), dim3(256), 0, g.stream, dc, (const float*)d_u, (const float*)d_v, n,
+                       (float*)d_o, (float*)d_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(org, d_o, 12 * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(dir, d_d, 12 * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RT_OK;
+}
+
+int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, const uint32_t* pixel, const uint32_t* sample,
+             uint32_t seed, uint32_t k0, float* rgb, rt_stats* stats) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_trace: call rt_init first");
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_trace: unknown scene");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return RT_OK;
+    if (!org || !dir || !pixel || !sample || !rgb) return fail(RT_E_INVALID, "rt_trace: null buffer");
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void *d_o, *d_d, *d_p, *d_s, *d_c, *d_cnt;
+    int rc;
+    if ((rc = tmp.get(&d_o, 12 * n)) || (rc = tmp.get(&d_d, 12 * n)) || (rc = tmp.get(&d_p, 4 * n)) || (rc = tmp.get(&d_s, 4 * n)) ||
+        (rc = tmp.get(&d_c, 12 * n)) || (rc = tmp.get(&d_cnt, 32)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(d_o, org, 12 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_d, dir, 12 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_p, pixel, 4 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_s, sample, 4 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, g.stream));
+    HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    hipLaunchKernelGGL(k_trace, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
+                       (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g.ev1, g.stream));
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(rgb, d_c, 12 * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 32, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world) {
+    if (!tile_w || !tile_h || !world || rank >= world) return 0;
+    uint64_t tiles = (uint64_t)((w + tile_w - 1) / tile_w) * ((h + tile_h - 1) / tile_h);
+    return (size_t)((tiles + world - 1 - rank) / world);
+}
+
+int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
+                     uint32_t tile_h, uint32_t rank, uint32_t world, float* d_rgb_tiles, uint64_t* d_counters3, void* hip_stream) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_render: call rt_init first");
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_render: unknown scene");
+    if (!cam || !d_rgb_tiles) return fail(RT_E_INVALID, "rt_render: null argument");
+    RenderParams rp;
+    int rc = make_render_params(w, h, spp, seed, tile_w, tile_h, rank, world, rp);
+    if (rc) return rc;
+    DCamera dc;
+    std::string err;
+    if (!rtb::invert_camera(*cam, dc, err)) return fail(RT_E_INVALID, err);
+    if (rp.n_local_tiles == 0) return RT_OK;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
+    uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
+    hipLaunchKernelGGL(k_render, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, r->dev, dc, rp, d_rgb_tiles, d_counters3);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
+              uint32_t tile_h, uint32_t rank, uint32_t world, float* rgb_tiles, rt_stats* stats) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_render: call rt_init first");
+    if (!rgb_tiles) return fail(RT_E_INVALID, "rt_render: null output");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    size_t n_tiles = rt_tiles_per_rank(w, h, tile_w, tile_h, rank, world);
+    size_t bytes = n_tiles * tile_w * tile_h * 3 * sizeof(float);
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void *d_out, *d_cnt;
+    int rc;
+    if ((rc = tmp.get(&d_out, bytes)) || (rc = tmp.get(&d_cnt, 32))) return rc;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, g.stream));
+    HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    if ((rc = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, rank, world, (float*)d_out, (uint64_t*)d_cnt, g.stream))) return rc;
+    HIP_TRY(hipEventRecord(g.ev1, g.stream));
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    if (bytes) HIP_TRY(hipMemcpyAsync(rgb_tiles, d_out, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 32, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+int rt_tiles_to_image(const float* gathered, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t world, float* rgb_image) {
+    if (!gathered || !rgb_image || !w || !h || !tile_w || !tile_h || !world) return fail(RT_E_INVALID, "rt_tiles_to_image: bad argument");
+    uint32_t tiles_x = (w + tile_w - 1) / tile_w, tiles_y = (h + tile_h - 1) / tile_h;
+    size_t per_rank = rt_tiles_per_rank(w, h, tile_w, tile_h, 0, world); /* rank 0 holds the most */
+    size_t tile_floats = (size_t)tile_w * tile_h * 3;
+    for (uint32_t t = 0; t < tiles_x * tiles_y; ++t) {
+        uint32_t rank = t % world, local = t / world;
+        const float* src = gathered + ((size_t)rank * per_rank + local) * tile_floats;
+        uint32_t x0 = (t % tiles_x) * tile_w, y0 = (t / tiles_x) * tile_h;
+        for (uint32_t yy = 0; yy < tile_h && y0 + yy < h; ++yy)
+            for (uint32_t xx = 0; xx < tile_w && x0 + xx < w; ++xx)
+                std::memcpy(rgb_image + 3 * ((size_t)(y0 + yy) * w + x0 + xx), src + 3 * ((size_t)yy * tile_w + xx), 12);
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

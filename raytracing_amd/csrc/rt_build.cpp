@@ -1,0 +1,238 @@
+/*
+ * rt_build.cpp -- host side of rt_scene_create: validates a flat scene, precomputes the
+ * ray-independent terms, builds the object-level kd-tree the way the reference does on the host
+ * (R/src/KDTree.cpp:363-519) and inverts the camera matrices (R/src/matrixUtilities.h:6-135).
+ *
+ * Built with -ffp-contract=off: every float operation here must round exactly like the
+ * reference's per-ray evaluation of the same expression.
+ */
+#include "rt_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace rtb {
+
+namespace {
+
+const float kInf = std::numeric_limits<float>::infinity();
+
+struct F3 { float x, y, z; };
+inline F3 ld(const float* p) { return {p[0], p[1], p[2]}; }
+inline void st(float* p, F3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+inline F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float len(F3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline float fmax_std(float a, float b) { return (a < b) ? b : a; }  /* std::max */
+inline float fmin_std(float a, float b) { return (b < a) ? b : a; }  /* std::min */
+
+struct Box { float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf}; };
+inline void grow(Box& b, const float* p) {  /* AABB::expandByPoint, R/src/AABB.h:76-84 */
+    for (int a = 0; a < 3; ++a) { b.lo[a] = fmin_std(b.lo[a], p[a]); b.hi[a] = fmax_std(b.hi[a], p[a]); }
+}
+
+/* box the kd builder assigns to one object, R/src/KDTree.cpp:393-416 */
+Box object_box(const rt_scene_desc& d, const DRef& r) {
+    Box b;
+    if (r.type == RT_SPHERE) {
+        const rt_sphere& s = d.spheres[r.object];
+        for (int a = 0; a < 3; ++a) { b.lo[a] = s.center[a] - s.radius; b.hi[a] = s.center[a] + s.radius; }
+    } else if (r.type == RT_SQUARE) {
+        const rt_square& q = d.squares[r.object];
+        for (int a = 0; a < 3; ++a) b.lo[a] = b.hi[a] = q.v[0][a];
+        for (int v = 1; v < 3; ++v)  /* vertices 1 and 2 only, as the reference loops */
+            for (int a = 0; a < 3; ++a) {
+                if (q.v[v][a] < b.lo[a]) b.lo[a] = q.v[v][a];
+                if (q.v[v][a] > b.hi[a]) b.hi[a] = q.v[v][a];
+            }
+    } else {
+        const rt_mesh& m = d.meshes[r.object];
+        for (int a = 0; a < 3; ++a) { b.lo[a] = m.aabb_min[a]; b.hi[a] = m.aabb_max[a]; }
+    }
+    return b;
+}
+
+/* KDTree::buildNode (V3), R/src/KDTree.cpp:363-473, on the index range [first, first+count) of
+ * out.refs.  The reference copies the list into two children in list order; a stable partition of
+ * the range is the same order, so every leaf is a contiguous slice. */
+int32_t build_node(const rt_scene_desc& d, Built& out, const Box& box, int32_t first, int32_t count, int32_t depth) {
+    int32_t id = (int32_t)out.kd.size();
+    out.kd.push_back(DKdNode{0, -1, 0.f, -1, -1, first, 0, depth});
+    auto leaf = [&]() { out.kd[id].leaf = 1; out.kd[id].n_refs = count; return id; };
+    if (count <= d.kd_max_leaf || depth >= d.kd_max_depth) return leaf();
+    float ex = box.hi[0] - box.lo[0], ey = box.hi[1] - box.lo[1], ez = box.hi[2] - box.lo[2];
+    if (fmax_std(fmax_std(ex, ey), ez) < d.kd_epsilon) return leaf();
+    int axis = 0;
+    if (ey >= ex && ey >= ez) axis = 1;
+    else if (ez >= ex && ez >= ey) axis = 2;
+    float cut = 0.f;
+    for (int32_t i = 0; i < count; ++i) {
+        Box b = object_box(d, out.refs[first + i]);
+        cut += (b.lo[axis] + b.hi[axis]) * 0.5f;
+    }
+    cut /= (float)(size_t)count;
+    auto goes_left = [&](const DRef& r) {
+        Box b = object_box(d, r);
+        return 0.5f * (b.lo[axis] + b.hi[axis]) <= cut;
+    };
+    auto mid = std::stable_partition(out.refs.begin() + first, out.refs.begin() + first + count, goes_left);
+    int32_t n_left = (int32_t)(mid - (out.refs.begin() + first));
+    out.kd[id].axis = axis;
+    out.kd[id].cut = cut;
+    if (n_left == 0 || n_left == count) return leaf();  /* list order is untouched in that case */
+    Box bl = box, br = box;
+    bl.hi[axis] = cut;
+    br.lo[axis] = cut;
+    int32_t l = build_node(d, out, bl, first, n_left, depth + 1);
+    int32_t r = build_node(d, out, br, first + n_left, count - n_left, depth + 1);
+    out.kd[id].left = l;
+    out.kd[id].right = r;
+    return id;
+}
+
+bool fail(std::string& err, const char* what) { err = what; return false; }
+
+}  // namespace
+
+bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
+    out = Built();
+    if ((d.n_spheres && !d.spheres) || (d.n_squares && !d.squares) || (d.n_meshes && !d.meshes) ||
+        (d.n_lights && !d.lights) || (d.n_materials && !d.materials))
+        return fail(err, "rt_scene_create: null array with non-zero count");
+    if (d.n_vertices && (!d.positions || !d.normals)) return fail(err, "rt_scene_create: null vertex arrays");
+    if (d.n_triangles && !d.triangles) return fail(err, "rt_scene_create: null triangle array");
+    auto mat_ok = [&](int32_t m) { return m >= 0 && (uint32_t)m < d.n_materials; };
+
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
+        const rt_material& m = d.materials[i];
+        DMaterial o{};
+        for (int a = 0; a < 3; ++a) { o.kd[a] = m.diffuse[a]; o.ks[a] = m.specular[a]; }
+        o.shininess = m.shininess; o.ior = m.index_medium; o.type = m.type;
+        out.materials.push_back(o);
+    }
+    for (uint32_t i = 0; i < d.n_spheres; ++i) {
+        const rt_sphere& s = d.spheres[i];
+        if (!mat_ok(s.material)) return fail(err, "rt_scene_create: sphere material index out of range");
+        DSphere o{};
+        for (int a = 0; a < 3; ++a) o.c[a] = s.center[a];
+        o.r = s.radius;
+        o.r2 = s.radius * s.radius;
+        o.mat = s.material;
+        out.spheres.push_back(o);
+    }
+    for (uint32_t i = 0; i < d.n_squares; ++i) {
+        const rt_square& q = d.squares[i];
+        if (!mat_ok(q.material)) return fail(err, "rt_scene_create: square material index out of range");
+        DSquare o{};
+        F3 v0 = ld(q.v[0]), w = ld(q.v[1]) - v0, h = ld(q.v[3]) - v0, n = cross(w, h);
+        st(o.v0, v0); st(o.w, w); st(o.h, h); st(o.n, n);
+        o.width = len(w); o.height = len(h);
+        float L = len(n);
+        o.nn[0] = n.x / L; o.nn[1] = n.y / L; o.nn[2] = n.z / L;
+        o.mat = q.material;
+        out.squares.push_back(o);
+    }
+    const float scaling = 1.000001f;  /* R/src/Mesh.h:220 */
+    for (uint32_t i = 0; i < d.n_meshes; ++i) {
+        const rt_mesh& m = d.meshes[i];
+        if (!mat_ok(m.material)) return fail(err, "rt_scene_create: mesh material index out of range");
+        if ((uint64_t)m.first_vertex + m.n_vertices > d.n_vertices || (uint64_t)m.first_triangle + m.n_triangles > d.n_triangles)
+            return fail(err, "rt_scene_create: mesh slice outside the vertex / triangle pools");
+        DMesh o{};
+        o.first_tri = (uint32_t)out.tris.size(); o.n_tris = m.n_triangles; o.mat = m.material; o.bvh_root = -1;
+        for (uint32_t t = 0; t < m.n_triangles; ++t) {
+            const uint32_t* idx = d.triangles + 3 * ((size_t)m.first_triangle + t);
+            if (idx[0] >= m.n_vertices || idx[1] >= m.n_vertices || idx[2] >= m.n_vertices)
+                return fail(err, "rt_scene_create: triangle vertex index out of range");
+            const float* P = d.positions + 3 * (size_t)m.first_vertex;
+            F3 v0 = scaling * ld(P + 3 * idx[0]), v1 = scaling * ld(P + 3 * idx[1]), v2 = scaling * ld(P + 3 * idx[2]);
+            DTri tr{};
+            st(tr.v0, v0); st(tr.e1, v1 - v0); st(tr.e2, v2 - v0);
+            tr.i0 = m.first_vertex + idx[0]; tr.i1 = m.first_vertex + idx[1]; tr.i2 = m.first_vertex + idx[2];
+            out.tris.push_back(tr);
+        }
+        out.meshes.push_back(o);
+    }
+    out.normals.assign(d.normals, d.normals + 3 * (size_t)d.n_vertices);
+    for (uint32_t i = 0; i < d.n_lights; ++i) {
+        const rt_light& l = d.lights[i];
+        DLight o{};
+        o.type = l.type;
+        for (int a = 0; a < 3; ++a) { o.pos[a] = l.pos[a]; o.color[a] = l.color[a]; o.p0[a] = l.p0[a]; o.p1[a] = l.p1[a]; o.p2[a] = l.p2[a]; }
+        out.lights.push_back(o);
+    }
+
+    /* root box: Scene::computeGlobalAABB, R/src/Scene.h:133-166 */
+    Box root;
+    for (uint32_t i = 0; i < d.n_meshes; ++i)
+        for (uint32_t v = 0; v < d.meshes[i].n_vertices; ++v) grow(root, d.positions + 3 * ((size_t)d.meshes[i].first_vertex + v));
+    for (uint32_t i = 0; i < d.n_squares; ++i)
+        for (int v = 0; v < 4; ++v) grow(root, d.squares[i].v[v]);
+    for (uint32_t i = 0; i < d.n_spheres; ++i) {
+        const rt_sphere& s = d.spheres[i];
+        float lo[3] = {s.center[0] - s.radius, s.center[1] - s.radius, s.center[2] - s.radius};
+        float hi[3] = {s.center[0] + s.radius, s.center[1] + s.radius, s.center[2] + s.radius};
+        grow(root, lo); grow(root, hi);
+    }
+    for (int a = 0; a < 3; ++a) { out.box_lo[a] = root.lo[a]; out.box_hi[a] = root.hi[a]; }
+
+    /* KDTree::buildKDTree, R/src/KDTree.cpp:477-519: spheres, squares, meshes */
+    for (uint32_t i = 0; i < d.n_spheres; ++i) out.refs.push_back(DRef{RT_SPHERE, (int32_t)i});
+    for (uint32_t i = 0; i < d.n_squares; ++i) out.refs.push_back(DRef{RT_SQUARE, (int32_t)i});
+    for (uint32_t i = 0; i < d.n_meshes; ++i) out.refs.push_back(DRef{RT_MESH, (int32_t)i});
+    build_node(d, out, root, 0, (int32_t)out.refs.size(), 0);
+    out.kd_epsilon = d.kd_epsilon;
+    return true;
+}
+
+/* 4x4 inverse by cofactors in the reference's term order (R/src/matrixUtilities.h:12-122).
+ * Each output element is six signed triple products; every index triple below is written as a
+ * three-digit hex number ijk, negative terms carry bit 12. */
+static const uint16_t kCofactor[16][6] = {
+    {0x05af, 0x15be, 0x196f, 0x097e, 0x0d6b, 0x1d7a}, {0x11af, 0x01be, 0x092f, 0x193e, 0x1d2b, 0x0d3a},
+    {0x016f, 0x117e, 0x152f, 0x053e, 0x0d27, 0x1d36}, {0x116b, 0x017a, 0x052b, 0x153a, 0x1927, 0x0936},
+    {0x14af, 0x04be, 0x086f, 0x187e, 0x1c6b, 0x0c7a}, {0x00af, 0x10be, 0x182f, 0x083e, 0x0c2b, 0x1c3a},
+    {0x106f, 0x007e, 0x042f, 0x143e, 0x1c27, 0x0c36}, {0x006b, 0x107a, 0x142b, 0x043a, 0x0827, 0x1836},
+    {0x049f, 0x14bd, 0x185f, 0x087d, 0x0c5b, 0x1c79}, {0x109f, 0x00bd, 0x081f, 0x183d, 0x1c1b, 0x0c39},
+    {0x005f, 0x107d, 0x141f, 0x043d, 0x0c17, 0x1c35}, {0x105b, 0x0079, 0x041b, 0x1439, 0x1817, 0x0835},
+    {0x149e, 0x04ad, 0x085e, 0x186d, 0x1c5a, 0x0c69}, {0x009e, 0x10ad, 0x181e, 0x082d, 0x0c1a, 0x1c29},
+    {0x105e, 0x006d, 0x041e, 0x142d, 0x1c16, 0x0c25}, {0x005a, 0x1069, 0x141a, 0x0429, 0x0816, 0x1825},
+};
+
+static bool invert4(const double m[16], double out[16]) {
+    double inv[16];
+    for (int o = 0; o < 16; ++o) {
+        double acc = 0.0;
+        for (int t = 0; t < 6; ++t) {
+            uint16_t c = kCofactor[o][t];
+            double p = m[(c >> 8) & 15] * m[(c >> 4) & 15] * m[c & 15];
+            bool neg = (c & 0x1000) != 0;
+            if (t == 0) acc = neg ? -p : p;
+            else acc = neg ? acc - p : acc + p;
+        }
+        inv[o] = acc;
+    }
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * det;
+    return true;
+}
+
+bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err) {
+    double p[16], mv[16];
+    for (int i = 0; i < 16; ++i) { p[i] = cam.projection[i]; mv[i] = cam.modelview[i]; }
+    if (!invert4(p, out.proj_inv) || !invert4(mv, out.mv_inv)) return fail(err, "camera matrix is singular");
+    out.depth_near = cam.depth_near;
+    /* cameraSpaceToWorldSpace(0,0,0), R/src/matrixUtilities.h:188-197 */
+    const double* m = out.mv_inv;
+    double r[4] = {m[0] * 0.0 + m[4] * 0.0 + m[8] * 0.0 + m[12] * 1.0, m[1] * 0.0 + m[5] * 0.0 + m[9] * 0.0 + m[13] * 1.0,
+                   m[2] * 0.0 + m[6] * 0.0 + m[10] * 0.0 + m[14] * 1.0, m[3] * 0.0 + m[7] * 0.0 + m[11] * 0.0 + m[15] * 1.0};
+    for (int a = 0; a < 3; ++a) out.eye[a] = (float)(r[a] / r[3]);
+    out.pad = 0.f;
+    return true;
+}
+
+}  // namespace rtb

@@ -1,0 +1,31 @@
+/* rt_build.h -- host-side scene preparation for the HIP path (see rt_build.cpp). */
+#ifndef RT_BUILD_H
+#define RT_BUILD_H
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtamd.h"
+#include "rt_types.h"
+
+namespace rtb {
+
+struct Built {
+    std::vector<DSphere> spheres;
+    std::vector<DSquare> squares;
+    std::vector<DMesh> meshes;
+    std::vector<DTri> tris;
+    std::vector<float> normals;
+    std::vector<DMaterial> materials;
+    std::vector<DLight> lights;
+    std::vector<DKdNode> kd;   /* kd[0] = root, pre-order */
+    std::vector<DRef> refs;    /* leaf slices, list order of the reference */
+    float box_lo[3], box_hi[3];
+    float kd_epsilon = 0.01f;
+};
+
+bool build_scene(const rt_scene_desc& d, Built& out, std::string& err);
+bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err);
+
+}  // namespace rtb
+#endif

@@ -1,0 +1,447 @@
+/*
+ * rt_device.h -- device functions of the intersection + shading path (gfx950, wave64).
+ *
+ * Numerics contract: every float expression below is evaluated with the operation order of the
+ * reference routine cited beside it, with plain IEEE binary32 add / mul / div / sqrt (the file is
+ * compiled with -ffp-contract=off and hipcc's default correctly rounded divide / sqrt), because
+ * the reference binary is x86-64 SSE code without fused multiply-add.  Hit / miss decisions and
+ * the closest object are therefore bit-exact; colours differ only through powf.
+ *
+ * Execution model: one lane follows one ray / one path.  The scene tables are read with
+ * wave-uniform indices (loop counters), so the compiler fetches them through the scalar cache
+ * into SGPRs and the vector ALUs only see per-ray data.
+ */
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/rtamd.h"
+#include "rt_types.h"
+
+#define RT_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+
+RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV float len3(f3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+RT_DEV f3 norm3(f3 a) { float L = len3(a); return mk3(a.x / L, a.y / L, a.z / L); } /* R/src/Vec3.h:34 */
+RT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+RT_DEV float max_std(float a, float b) { return (a < b) ? b : a; } /* std::max, NaN behaviour included */
+RT_DEV float min_std(float a, float b) { return (b < a) ? b : a; } /* std::min */
+
+#define RT_INF __builtin_inff()
+
+/* per-lane work counters; summed over the wave and added to global memory once per wave */
+struct Cnt { uint32_t rays, nodes; };
+
+/* closest hit so far: enough to rebuild position and normal of the winner afterwards */
+struct HitRec {
+    float t;    /* +inf while nothing was hit */
+    int type;   /* RT_* or -1 */
+    int obj;
+    int tri;    /* global triangle id for a mesh hit */
+    float u, v; /* barycentrics of a mesh hit */
+};
+
+struct FullHit {
+    bool hit;
+    int type, obj, tri;
+    float t;
+    f3 p, n;
+};
+
+/* ---- AABB::intersectRayAABB, R/src/AABB.h:30-73 ---------------------------------------- */
+RT_DEV bool box_test(const float lo[3], const float hi[3], f3 o, f3 d, float& t_in, float& t_out) {
+    t_in = -RT_INF;
+    t_out = RT_INF;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float oo = comp(o, a), dd = comp(d, a);
+        if (__builtin_fabsf(dd) < 1e-8f) {
+            if (oo < lo[a] || oo > hi[a]) return false;
+            continue;
+        }
+        float t1 = (lo[a] - oo) / dd, t2 = (hi[a] - oo) / dd;
+        if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+        t_in = max_std(t_in, t1);
+        t_out = min_std(t_out, t2);
+        if (t_in > t_out) return false;
+    }
+    return t_out >= 0.0f;
+}
+
+/* ---- Sphere::intersect, R/src/Sphere.h:85-162: distance only ---------------------------- */
+RT_DEV bool sphere_t(const DSphere& s, f3 o, f3 d, float& t) {
+    f3 oc = o - ld3(s.c);
+    float a = dot3(d, d);
+    float b = dot3(2.f * d, oc);
+    float n = len3(oc);
+    float c = (n * n) - s.r2;
+    float delta = b * b - 4.f * a * c;
+    if (delta > 0.f) {
+        float sq = __builtin_sqrtf(delta);
+        float a2 = 2.f * a;
+        float t1 = (-b - sq) / a2, t2 = (-b + sq) / a2;
+        if (t1 > 0.f && t2 > 0.f) t = min_std(t1, t2);
+        else if (t1 > 0.f) t = t1;
+        else if (t2 > 0.f) t = t2;
+        else return false;
+        return true;
+    }
+    if (delta == 0.f) {
+        t = -b / (2.f * a);
+        return t > 0.f;
+    }
+    return false;
+}
+
+/* ---- Square::intersect, R/src/Square.h:63-115: distance only ---------------------------- */
+RT_DEV bool square_t(const DSquare& q, f3 o, f3 d, float& t) {
+    f3 v0 = ld3(q.v0), n = ld3(q.n);
+    float tt = dot3(v0 - o, n) / dot3(d, n);
+    if (tt >= 0.f) {
+        f3 bp = (o + tt * d) - v0;
+        float pw = dot3(bp, ld3(q.w)) / q.width, ph = dot3(bp, ld3(q.h)) / q.height;
+        if (0.f < pw && pw < q.width && 0.f < ph && ph < q.height) { t = tt; return true; }
+    }
+    return false; /* t < 0, rectangle missed, or t is NaN (undefined in the reference) */
+}
+
+/* ---- one triangle of Mesh::intersect, R/src/Mesh.h:225-257 ------------------------------ */
+RT_DEV bool tri_t(const DTri& tr, f3 o, f3 d, float& t, float& u, float& v) {
+    f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    f3 h = cross3(d, e2);
+    float a = dot3(e1, h);
+    if (__builtin_fabsf(a) < 1e-6f) return false;
+    float f = 1.0f / a;
+    f3 s = o - ld3(tr.v0);
+    u = f * dot3(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q = cross3(s, e1);
+    v = f * dot3(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = f * dot3(e2, q);
+    return true;
+}
+
+/* ---- Mesh::intersect closest loop, R/src/Mesh.h:225-277 (brute force over the slice) ----- */
+RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float& best_t, int& best_tri, float& best_u, float& best_v) {
+    bool found = false;
+    best_t = 3.402823466e+38f; /* FLT_MAX */
+    for (uint32_t i = 0; i < m.n_tris; ++i) {
+        float t, u, v;
+        if (tri_t(sc.tris[m.first_tri + i], o, d, t, u, v) && t > 1e-6f && t < best_t) {
+            best_t = t; best_tri = (int)(m.first_tri + i); best_u = u; best_v = v; found = true;
+        }
+    }
+    return found;
+}
+RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist) {
+    for (uint32_t i = 0; i < m.n_tris; ++i) {
+        float t, u, v;
+        if (tri_t(sc.tris[m.first_tri + i], o, d, t, u, v) && t > 1e-6f && t < dist) return true;
+    }
+    return false;
+}
+
+/* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------ */
+RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, HitRec& best) {
+    bool any = false;
+    for (int r = first; r < first + count; ++r) {
+        DRef ref = sc.refs[r];
+        float t = 0.f, u = 0.f, v = 0.f;
+        int tri = -1;
+        bool ok;
+        if (ref.type == RT_SPHERE) ok = sphere_t(sc.spheres[ref.object], o, d, t);
+        else if (ref.type == RT_SQUARE) ok = square_t(sc.squares[ref.object], o, d, t);
+        else ok = mesh_closest(sc, sc.meshes[ref.object], o, d, t, tri, u, v);
+        if (ok) {
+            any = true;
+            if (best.type < 0 || t < best.t) { best.t = t; best.type = ref.type; best.obj = ref.object; best.tri = tri; best.u = u; best.v = v; }
+        }
+    }
+    return any;
+}
+/* shadow query on a leaf: "closest hit exists and its t < dist" == "some object reports t < dist" */
+RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist) {
+    for (int r = first; r < first + count; ++r) {
+        DRef ref = sc.refs[r];
+        float t;
+        if (ref.type == RT_SPHERE) { if (sphere_t(sc.spheres[ref.object], o, d, t) && t < dist) return true; }
+        else if (ref.type == RT_SQUARE) { if (square_t(sc.squares[ref.object], o, d, t) && t < dist) return true; }
+        else { if (mesh_any(sc, sc.meshes[ref.object], o, d, dist)) return true; }
+    }
+    return false;
+}
+
+/* ---- KDTree::intersectNode for internal nodes, R/src/KDTree.cpp:600-676 -------------------
+ * The recursion is unrolled into a loop with one frame per "ray crosses the plane" level.  The
+ * boolean each call returns (something in that subtree was hit) is kept, because the reference
+ * uses it to decide whether the far child is visited. */
+#define RT_KD_MAX_DEPTH 16
+RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_out, HitRec& best) {
+    /* frame = far child id * 4 + state, plane distance, exit distance of the level.
+     * state 0: near subtree running; 1 / 2: far subtree running after near returned false / true */
+    int f_node[RT_KD_MAX_DEPTH];
+    float f_split[RT_KD_MAX_DEPTH], f_out[RT_KD_MAX_DEPTH];
+    int sp = 0, node = 0;
+    bool ret = false;
+    for (;;) {
+        for (;;) { /* descend until a leaf */
+            DKdNode nd = sc.kd[node];
+            if (nd.leaf) { ret = leaf_closest(sc, nd.first_ref, nd.n_refs, o, d, best); break; }
+            float da = comp(d, nd.axis), oa = comp(o, nd.axis);
+            float t_split = (__builtin_fabsf(da) < sc.kd_epsilon) ? RT_INF : (nd.cut - oa) / da;
+            int near_id = (da >= 0.f) ? nd.left : nd.right;
+            int far_id = (da >= 0.f) ? nd.right : nd.left;
+            if (t_split <= t_in) node = far_id;
+            else if (t_split >= t_out) node = near_id;
+            else {
+                if (sp >= RT_KD_MAX_DEPTH) return ret; /* unreachable: the host rejects deeper trees */
+                f_node[sp] = far_id * 4; f_split[sp] = t_split; f_out[sp] = t_out; ++sp;
+                node = near_id; t_out = t_split;
+            }
+        }
+        bool resumed = false;
+        while (sp > 0) { /* hand `ret` back to the waiting levels */
+            int k = sp - 1;
+            int state = f_node[k] & 3;
+            if (state == 0) {
+                bool hit_near = ret;
+                if (!hit_near || best.t > f_split[k]) {
+                    node = f_node[k] >> 2; t_in = f_split[k]; t_out = f_out[k];
+                    f_node[k] |= hit_near ? 2 : 1;
+                    resumed = true;
+                    break;
+                }
+                --sp; /* this level returns hit_near || false */
+            } else {
+                ret = (state == 2) || ret;
+                --sp;
+            }
+        }
+        if (!resumed) return ret;
+    }
+}
+
+/* ---- Scene::computeIntersection, R/src/Scene.h:169-205 via KDTree::intersect :679-687 ----- */
+RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
+    ++cnt.rays;
+    HitRec best;
+    best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
+    float t_in, t_out;
+    if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
+    if (sc.root_is_leaf) leaf_closest(sc, 0, (int)sc.n_refs, o, d, best);
+    else kd_closest(sc, o, d, t_in, t_out, best);
+    return best;
+}
+
+/* position / normal of the winner, exactly what its own intersect routine would have stored */
+RT_DEV FullHit finish_hit(const DeviceScene& sc, const HitRec& r, f3 o, f3 d) {
+    FullHit h;
+    h.hit = r.type >= 0; h.type = r.type; h.obj = r.obj; h.tri = r.tri; h.t = r.t;
+    h.p = mk3(0.f, 0.f, 0.f); h.n = mk3(0.f, 0.f, 0.f);
+    if (!h.hit) return h;
+    h.p = o + r.t * d;
+    if (r.type == RT_SPHERE) h.n = norm3(h.p - ld3(sc.spheres[r.obj].c));                  /* Sphere.h:120-122 */
+    else if (r.type == RT_SQUARE) h.n = ld3(sc.squares[r.obj].nn);                         /* Square.h:108-109 */
+    else {                                                                                  /* Mesh.h:267-272 */
+        DTri tr = sc.tris[r.tri];
+        f3 n0 = ld3(sc.normals + 3 * (size_t)tr.i0), n1 = ld3(sc.normals + 3 * (size_t)tr.i1), n2 = ld3(sc.normals + 3 * (size_t)tr.i2);
+        h.n = norm3(((1.0f - r.u - r.v) * n0 + r.u * n1) + r.v * n2);
+    }
+    return h;
+}
+
+/* shadow test of Scene::phong, R/src/Scene.h:379-384: closest hit exists and t < dist */
+RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
+    ++cnt.rays;
+    float t_in, t_out;
+    if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return false;
+    if (sc.root_is_leaf) return leaf_any(sc, 0, (int)sc.n_refs, o, d, dist);
+    HitRec best;
+    best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
+    return kd_closest(sc, o, d, t_in, t_out, best) && best.type >= 0 && best.t < dist;
+}
+
+/* ---- random numbers ---------------------------------------------------------------------- */
+struct Rng {
+    uint32_t key, k;
+    /* (float)rand() / RAND_MAX with RAND_MAX converted to float = 2^31 (R/src/Scene.h:259-260) */
+    RT_DEV float unit() { return (float)(int)rt_rand31(key, k++) / 2147483648.f; }
+};
+
+/* powf(x, y) for x >= 0 through double: x^16 (the Cornell shininess) by four exact-enough double
+ * squarings, anything else through the double pow; rounded once to float. */
+RT_DEV float pow_shiny(float x, float y) {
+    if (y == 16.0f) { double a = (double)x; a *= a; a *= a; a *= a; a *= a; return (float)a; }
+    if (y == 0.0f) return 1.0f;
+    return (float)pow((double)x, (double)y);
+}
+
+/* Scene::computeLightContribution, R/src/Scene.h:304-316 */
+RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V, f3 L) {
+    f3 R = norm3((2.f * dot3(N, L)) * N - L);
+    float nl = max_std(0.f, dot3(L, N));
+    float sp = pow_shiny(max_std(0.f, dot3(R, V)), m.shininess);
+    sum.x += lt.color[0] * m.kd[0] * nl; sum.x += lt.color[0] * m.ks[0] * sp;
+    sum.y += lt.color[1] * m.kd[1] * nl; sum.y += lt.color[1] * m.ks[1] * sp;
+    sum.z += lt.color[2] * m.kd[2] * nl; sum.z += lt.color[2] * m.ks[2] * sp;
+}
+
+RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
+    return type == RT_SPHERE ? sc.spheres[obj].mat : (type == RT_SQUARE ? sc.squares[obj].mat : sc.meshes[obj].mat);
+}
+
+/* ---- Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276) ------------------ */
+RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
+    ++cnt.nodes;
+    const DMaterial m = sc.materials[material_index(sc, h.type, h.obj)];
+    f3 ambient = 0.35f * mk3(0.2f, 0.2f, 0.2f);
+    f3 diffuse = mk3(0.f, 0.f, 0.f), specular = mk3(0.f, 0.f, 0.f);
+    const f3 P = h.p;
+    const f3 N = norm3(h.n);
+    const f3 V = norm3(-1.f * P);              /* camera assumed at the world origin */
+    const f3 so = P + 0.001f * N;              /* shadow-ray origin */
+    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+        const DLight lt = sc.lights[li];
+        if (lt.type == RT_LIGHT_QUAD) {
+            f3 sum = mk3(0.f, 0.f, 0.f);
+            f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
+            for (int i = 0; i < 16; ++i) {
+                float u = rng.unit();
+                float v = rng.unit();
+                if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+                f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
+                f3 SP = S - P;
+                f3 L = norm3(SP);
+                if (occluded(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
+                light_term(sum, lt, m, N, V, L);
+            }
+            sum = sum / 16.f;
+            diffuse = diffuse + sum;
+            specular = specular + sum; /* the reference adds the quad-light term to both sums */
+        } else {
+            f3 SP = ld3(lt.pos) - P;
+            f3 L = norm3(SP);
+            if (occluded(sc, so, norm3(L), len3(SP), cnt)) continue;
+            light_term(diffuse, lt, m, N, V, L);
+        }
+    }
+    return (ambient + diffuse) + specular;
+}
+
+/* ---- Scene::rayTraceRecursive, R/src/Scene.h:596-713, as a loop --------------------------
+ * The recursion (depth <= 11, reflected child before refracted child) becomes a loop over
+ * "calls" with a small per-lane frame stack; the colour arithmetic on the way back up is the
+ * reference's, in the reference's order, so the result does not depend on the rewrite.
+ * frame layout (8 floats): kind, F, a[3], b[3]
+ *   kind 1 mirror : a = phong colour of the node, b = specular_material
+ *   kind 2 glass, reflected child running : a = refracted origin, b = refracted direction
+ *   kind 3 glass, reflected child running, no refracted ray (total internal reflection)
+ *   kind 4 glass, refracted child running : a = reflected colour */
+#define RT_MAX_BOUNCES 10
+RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
+    float stk[RT_MAX_BOUNCES][8];
+    int sp = 0;
+    f3 ret = mk3(0.f, 0.f, 0.f);
+    for (;;) {
+        HitRec rec = closest_rec(sc, o, d, cnt);
+        bool descended = false;
+        if (rec.type < 0) ret = mk3(0.f, 0.f, 0.f);
+        else {
+            FullHit h = finish_hit(sc, rec, o, d);
+            f3 col = shade(sc, h, rng, cnt);
+            ret = col;
+            if (sp < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
+                const DMaterial m = sc.materials[sc.spheres[h.obj].mat];
+                f3 P = h.p, N = h.n, I = d;
+                if (m.type == RT_MAT_MIRROR) {
+                    f3 R = I - (2.0f * dot3(I, N)) * N;
+                    float* f = stk[sp++];
+                    f[0] = 1.f; f[1] = 0.f; f[2] = col.x; f[3] = col.y; f[4] = col.z; f[5] = m.ks[0]; f[6] = m.ks[1]; f[7] = m.ks[2];
+                    o = P + 0.001f * N; d = norm3(R);
+                    descended = true;
+                } else if (m.type == RT_MAT_GLASS) {
+                    float n1 = 1.0f, n2 = m.ior;
+                    if (dot3(I, N) > 0.0f) { float s = n1; n1 = n2; n2 = s; N = -1.0f * N; }
+                    float cosI = __builtin_fabsf(dot3(I, N));
+                    float eta = n1 / n2;
+                    float sinT2 = eta * eta * (1.0f - cosI * cosI);
+                    float F;
+                    if (sinT2 > 1.0f) F = 1.0f;
+                    else {
+                        float cosT = __builtin_sqrtf(1.0f - sinT2);
+                        float rs = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+                        float rp = (n1 * cosT - n2 * cosI) / (n1 * cosT + n2 * cosI);
+                        /* pow(x, 2) in double = exact square rounded once = the float product */
+                        F = (rs * rs + rp * rp) / 2.0f;
+                    }
+                    f3 R = I - (2.0f * dot3(I, N)) * N;
+                    float* f = stk[sp++];
+                    f[1] = F;
+                    if (F < 1.0f) {
+                        f3 T = eta * (I - cosI * N) - __builtin_sqrtf(1.0f - sinT2) * N;
+                        f3 to = P - 0.001f * N, td = norm3(T);
+                        f[0] = 2.f; f[2] = to.x; f[3] = to.y; f[4] = to.z; f[5] = td.x; f[6] = td.y; f[7] = td.z;
+                    } else f[0] = 3.f;
+                    o = P + 0.001f * N; d = norm3(R);
+                    descended = true;
+                }
+            }
+        }
+        if (descended) continue;
+        bool resumed = false;
+        while (sp > 0) {
+            float* f = stk[sp - 1];
+            int kind = (int)f[0];
+            if (kind == 1) {
+                ret = mk3(f[2] + ret.x * f[5], f[3] + ret.y * f[6], f[4] + ret.z * f[7]);
+                --sp;
+            } else if (kind == 2) {
+                o = mk3(f[2], f[3], f[4]); d = mk3(f[5], f[6], f[7]);
+                f[0] = 4.f; f[2] = ret.x; f[3] = ret.y; f[4] = ret.z;
+                resumed = true;
+                break;
+            } else if (kind == 3) {
+                ret = f[1] * ret + (1.0f - f[1]) * mk3(0.f, 0.f, 0.f);
+                --sp;
+            } else {
+                ret = f[1] * mk3(f[2], f[3], f[4]) + (1.0f - f[1]) * ret;
+                --sp;
+            }
+        }
+        if (!resumed) return ret;
+    }
+}
+
+/* ---- screen_space_to_world_space_ray, R/src/matrixUtilities.h:198-222 --------------------
+ * double arithmetic exactly as the reference; the direction comes back normalised once. */
+RT_DEV void primary_ray(const DCamera& cam, float u, float v, f3& o, f3& d) {
+    double x = (double)2.f * (double)u - (double)1.f;
+    double y = -((double)2.f * (double)v - (double)1.f);
+    double z = cam.depth_near, w = 1.0;
+    const double* A = cam.proj_inv;
+    double a0 = A[0] * x + A[4] * y + A[8] * z + A[12] * w;
+    double a1 = A[1] * x + A[5] * y + A[9] * z + A[13] * w;
+    double a2 = A[2] * x + A[6] * y + A[10] * z + A[14] * w;
+    double a3 = A[3] * x + A[7] * y + A[11] * z + A[15] * w;
+    const double* B = cam.mv_inv;
+    double b0 = B[0] * a0 + B[4] * a1 + B[8] * a2 + B[12] * a3;
+    double b1 = B[1] * a0 + B[5] * a1 + B[9] * a2 + B[13] * a3;
+    double b2 = B[2] * a0 + B[6] * a1 + B[10] * a2 + B[14] * a3;
+    double b3 = B[3] * a0 + B[7] * a1 + B[11] * a2 + B[15] * a3;
+    f3 world = mk3((float)(b0 / b3), (float)(b1 / b3), (float)(b2 / b3));
+    o = ld3(cam.eye);
+    d = norm3(world - o);
+}
+
+#endif /* RT_DEVICE_H */

@@ -1,0 +1,93 @@
+/*
+ * rt_types.h -- device-side scene layout shared by the host builder (rt_build.cpp) and the HIP
+ * kernels (rt_api.hip).
+ *
+ * Everything a ray needs that does not depend on the ray is computed once on the host with the
+ * same binary32 operations the reference evaluates per ray (host code is built with
+ * -ffp-contract=off), so reading it back is bit-identical to recomputing it:
+ *   square: edge vectors, their cross product, its normalisation, the two edge lengths
+ *           (R/src/Square.h:80-84, 98-99, 108-109)
+ *   sphere: radius * radius (R/src/Sphere.h:104)
+ *   triangle: the three vertices scaled by 1.000001f and the two edges (R/src/Mesh.h:220-234)
+ * Records are 16-byte multiples so a wave-uniform record is fetched with scalar dwordx4 loads.
+ */
+#ifndef RT_TYPES_H
+#define RT_TYPES_H
+
+#include <stdint.h>
+
+struct DSphere {  /* 32 B */
+    float c[3]; float r;
+    float r2; int32_t mat; int32_t pad[2];
+};
+
+struct DSquare {  /* 80 B */
+    float v0[3]; float width;
+    float w[3]; float height;
+    float h[3]; int32_t mat;
+    float n[3]; float pad0;   /* cross(w, h), not normalised */
+    float nn[3]; float pad1;  /* normalize(n) */
+};
+
+struct DMaterial {  /* 48 B */
+    float kd[3]; float shininess;
+    float ks[3]; float ior;
+    int32_t type; int32_t pad[3];
+};
+
+struct DLight {  /* 80 B */
+    float pos[3]; int32_t type;
+    float color[3]; float pad0;
+    float p0[3]; float pad1;
+    float p1[3]; float pad2;
+    float p2[3]; float pad3;
+};
+
+struct DTri {  /* 48 B: one Moller-Trumbore test reads exactly this */
+    float v0[3]; uint32_t i0;  /* i0..i2: vertex ids into DeviceScene::normals (global) */
+    float e1[3]; uint32_t i1;
+    float e2[3]; uint32_t i2;
+};
+
+struct DMesh {  /* 32 B */
+    uint32_t first_tri, n_tris;
+    int32_t mat;
+    int32_t bvh_root;  /* index into bvh nodes, -1 = brute force over the triangle range */
+    int32_t pad[4];
+};
+
+/* Object-level kd-tree node, R/src/KDTree.h:12-29, children by index, leaf refs by range. */
+struct DKdNode {  /* 32 B */
+    int32_t leaf; int32_t axis; float cut; int32_t left;
+    int32_t right; int32_t first_ref; int32_t n_refs; int32_t depth;
+};
+
+struct DRef { int32_t type; int32_t object; };
+
+struct DeviceScene {
+    const DSphere* spheres;
+    const DSquare* squares;
+    const DMesh* meshes;
+    const DTri* tris;
+    const float* normals;  /* xyz per vertex */
+    const DMaterial* materials;
+    const DLight* lights;
+    const DKdNode* kd;
+    const DRef* refs;
+    uint32_t n_spheres, n_squares, n_meshes, n_lights;
+    uint32_t n_kd, n_refs;
+    float box_lo[3], box_hi[3];  /* root box = Scene::computeGlobalAABB */
+    float kd_epsilon;
+    int32_t root_is_leaf;
+};
+
+/* Inverted camera matrices, R/src/matrixUtilities.h:188-217, done once on the host in double. */
+struct DCamera {
+    double proj_inv[16];
+    double mv_inv[16];
+    double depth_near;
+    float eye[3];
+    float pad;
+};
+
+#endif

@@ -1,0 +1,180 @@
+"""GPU parity: the HIP path (through the C-ABI of include/rtamd.h) against the CPU oracle on the
+same seeded inputs.  Bit-exact for hit / type / object / triangle index, t, position and normal;
+colours within the stated tolerance (they differ only through powf).  Run with -m gpu."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracing_amd import api
+from tests import rayset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    api.init(0)
+    yield
+
+
+@pytest.fixture(scope="module", params=[0, 1, 2, 3])
+def scene_pair(request):
+    o = orc.Scene.builtin(request.param)
+    g = api.DeviceScene(o.desc, keep=o)
+    yield request.param, o, g
+    g.close()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_hits_equal(a, b, what):
+    for f in ("hit", "type", "object", "tri"):
+        bad = np.nonzero(a[f] != b[f])[0]
+        assert bad.size == 0, f"{what}: {f} differs on {bad.size} rays, first {bad[:5]}: {a[f][bad[:5]]} vs {b[f][bad[:5]]}"
+    for f in ("t", "p", "n"):
+        bad = np.nonzero((_bits(a[f]) != _bits(b[f])).reshape(len(a), -1).any(axis=1))[0]
+        assert bad.size == 0, f"{what}: {f} bits differ on {bad.size} rays, first {bad[:5]}"
+
+
+def test_generate_rays_bit_exact():
+    rng = np.random.default_rng(3)
+    u = rng.random(20000).astype(np.float32)
+    v = rng.random(20000).astype(np.float32)
+    u[:4] = [0.0, 1.0, 0.5, 1.0]
+    v[:4] = [0.0, 1.0, 0.5, 0.0]
+    for w, h in ((480, 480), (1920, 1080)):
+        cam = orc.camera_default(w, h)
+        oo, od = orc.generate_rays(cam, u, v)
+        go, gd = api.generate_rays(cam, u, v)
+        assert np.array_equal(_bits(oo), _bits(go)) and np.array_equal(_bits(od), _bits(gd))
+    # a rotated, shifted camera: general (dense) matrices through the cofactor inverse
+    q = np.array([0.1, -0.2, 0.3, 0.9], np.float32)
+    q /= np.float32(np.linalg.norm(q))
+    cam = orc.camera_build(45.0, 4.1, 10000.0, 640, 360, 0.3, -0.2, -3.1, 3.0, q)
+    oo, od = orc.generate_rays(cam, u, v)
+    go, gd = api.generate_rays(cam, u, v)
+    assert np.array_equal(_bits(oo), _bits(go)) and np.array_equal(_bits(od), _bits(gd))
+
+
+def test_kdtree_matches_oracle(scene_pair):
+    _, o, g = scene_pair
+    on, orf, ob = o.kdtree()
+    gn, grf, gb = g.kdtree()
+    assert np.array_equal(on, gn) and np.array_equal(orf, grf) and np.array_equal(_bits(ob), _bits(gb))
+
+
+def test_intersect_bit_exact(scene_pair):
+    sid, o, g = scene_pair
+    org, d = rayset.mixed(orc)
+    a = o.intersect(org, d)
+    b = g.intersect(org, d)
+    assert a["hit"].sum() > 1000
+    assert_hits_equal(a, b, f"scene {sid}")
+
+
+def test_mesh_intersect_tindex():
+    o = orc.Scene.builtin(3)
+    g = api.DeviceScene(o.desc, keep=o)
+    org, d = rayset.interior_rays(20000, seed=23)
+    tgt = np.random.default_rng(5).uniform(-0.6, 0.6, (20000, 3)).astype(np.float32) + np.float32([0, -1.3, 0])
+    d = (tgt - org).astype(np.float32)
+    a = o.mesh_intersect(0, org, d)
+    b = g.mesh_intersect(0, org, d)
+    assert a["hit"].sum() > 2000 and len(np.unique(a["tri"][a["hit"] == 1])) == 24
+    assert_hits_equal(a, b, "star mesh")
+    g.close()
+
+
+def test_empty_batch_and_errors(scene_pair):
+    _, _, g = scene_pair
+    assert len(g.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
+    with pytest.raises(api.RtError):
+        api.check(api.lib().rt_scene_destroy(987654321))
+    bad = orc.Scene.builtin(2)
+    d = api.copy_struct(api.SceneDesc, bad.desc)
+    d.n_spheres = 1
+    sph = (api.Sphere * 1)()
+    sph[0].material = 99
+    d.spheres = sph
+    with pytest.raises(api.RtError):
+        api.DeviceScene(d)
+
+
+# colours: identical arithmetic except powf (glibc powf on the CPU, double-precision power rounded
+# once on the GPU) -> a unit-in-the-last-place effect on the specular term
+COLOR_ATOL = 2e-6
+
+
+def test_trace_per_sample_colors(scene_pair):
+    sid, o, g = scene_pair
+    w, h, spp = 64, 64, 4
+    rng = np.random.default_rng(29)
+    ys, xs = np.mgrid[0:h, 0:w]
+    pix = np.repeat((xs + ys * w).ravel().astype(np.uint32), spp)
+    smp = np.tile(np.arange(spp, dtype=np.uint32), w * h)
+    u = ((np.repeat(xs.ravel(), spp) + rng.random(pix.size)) / w).astype(np.float32)
+    v = ((np.repeat(ys.ravel(), spp) + rng.random(pix.size)) / h).astype(np.float32)
+    org, d = orc.generate_rays(orc.camera_default(w, h), u, v)
+    oc, ost = o.trace(org, d, pix, smp, seed=1, k0=2)
+    gc, gst = g.trace(org, d, pix, smp, seed=1, k0=2)
+    assert (ost.rays, ost.samples, ost.nodes) == (gst.rays, gst.samples, gst.nodes)
+    assert np.isfinite(gc).all()
+    assert np.abs(oc - gc).max() <= COLOR_ATOL, np.abs(oc - gc).max()
+
+
+def psnr(a, b):
+    mse = np.mean((np.clip(a, 0, 1).astype(np.float64) - np.clip(b, 0, 1)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+def test_render_image_psnr(scene_pair):
+    sid, o, g = scene_pair
+    w, h, spp = 96, 54, 6
+    cam = orc.camera_default(w, h)
+    oi, ost = o.render(cam, w, h, spp, orc.RT_RNG_COUNTER, seed=5, threads=4)
+    gi, gst = g.render(cam, w, h, spp, seed=5, tile_w=16, tile_h=8)
+    assert (ost.rays, ost.samples, ost.nodes) == (gst.rays, gst.samples, gst.nodes)
+    assert psnr(oi, gi) >= 40.0  # the acceptance bar; in practice the images agree to ~1e-6
+    assert np.abs(oi - gi).max() <= COLOR_ATOL
+    assert np.array_equal(orc.quantize(oi), orc.quantize(gi)) or (orc.quantize(oi) != orc.quantize(gi)).mean() < 1e-3
+
+
+def test_tile_sharding_is_exact():
+    """Rendering the tiles of 2 or 3 ranks separately and scattering them gives the 1-rank image bit for bit
+    (ragged image size: 100 x 37 is not a multiple of the tile)."""
+    o = orc.Scene.builtin(2)
+    g = api.DeviceScene(o.desc, keep=o)
+    w, h, spp, tw, th = 100, 37, 3, 16, 8
+    cam = orc.camera_default(w, h)
+    ref, _ = g.render(cam, w, h, spp, seed=9, tile_w=tw, tile_h=th)
+    for world in (2, 3):
+        per = api.tiles_per_rank(w, h, tw, th, 0, world)
+        buf = np.zeros((world, per * th * tw * 3), np.float32)
+        rays = 0
+        for r in range(world):
+            tiles, st = g.render_tiles(cam, w, h, spp, 9, tw, th, r, world)
+            buf[r, :tiles.size] = tiles.ravel()
+            rays += st.rays
+        img = api.tiles_to_image(buf, w, h, tw, th, world)
+        assert np.array_equal(_bits(img), _bits(ref))
+    g.close()
+
+
+def test_scene3_matches_reference_render_statistically(golden_dir):
+    """The GPU render of scene 3 (50 spp, counter RNG) against the reference's own rendu.ppm: different
+    random numbers, same estimator, so the images agree up to Monte-Carlo noise."""
+    gold = np.load(os.path.join(golden_dir, "rendu_scene3_480x480_50spp.npz"))["rgb"].astype(np.float64) / 255
+    o = orc.Scene.builtin(3)
+    g = api.DeviceScene(o.desc, keep=o)
+    img, st = g.render(orc.camera_default(480, 480), 480, 480, 50, seed=1)
+    # 1 primary + 16 shadow rays per sample, minus the few samples whose primary ray slips between two walls
+    assert st.samples == 480 * 480 * 50 and 16.999 * st.samples < st.rays <= 17 * st.samples
+    q = orc.quantize(img).astype(np.float64) / 255
+    assert abs(q.mean() - gold.mean()) < 2e-3
+    assert psnr(q, gold) > 30.0
+    g.close()
