@@ -8,7 +8,8 @@
  * Conventions: plain C types only; every function returns 0 on success and a negative
  * RT_E_* code on failure (rt_last_error() gives the text); no exceptions cross the boundary;
  * output buffers are caller-owned; calls are blocking unless the name ends in _device (then
- * the work is enqueued on the given HIP stream and the pointers are device pointers);
+ * the work is enqueued on the given HIP stream -- NULL is HIP's default stream -- and the pointers
+ * are device pointers);
  * thread-compatible, not thread-safe; one process drives one GPU (rt_init picks it).
  */
 #ifndef RTAMD_H
@@ -125,9 +126,12 @@ typedef struct rt_hit {
     int32_t object; /* objectIndex, -1 on a miss                                            */
     int32_t tri;    /* tIndex of the closest triangle for a mesh hit, else -1               */
     float t;        /* FLT_MAX on a miss                                                    */
-    float p[3];
-    float n[3];
-    float pad_;
+    float u, v;     /* mesh hit: barycentrics (w1 = u, w2 = v, w0 = 1 - u - v), else 0      */
+    float pad0_;
+    float p[3];     /* intersection point                                                   */
+    float pad1_;
+    float n[3];     /* unit normal                                                          */
+    float pad2_;
 } rt_hit;
 
 typedef struct rt_stats {

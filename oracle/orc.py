@@ -61,8 +61,9 @@ class Stats(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri", "<i4"), ("t", "<f4"),
-                      ("p", "<f4", 3), ("n", "<f4", 3), ("pad", "<f4")])
-assert HIT_DTYPE.itemsize == 48
+                      ("u", "<f4"), ("v", "<f4"), ("pad0", "<f4"), ("p", "<f4", 3), ("pad1", "<f4"),
+                      ("n", "<f4", 3), ("pad2", "<f4")])
+assert HIT_DTYPE.itemsize == 64
 
 COUNTER_NAMES = ["rays", "samples", "nodes", "aabb", "sph_miss", "sph_hit", "sq_behind", "sq_reject", "sq_hit",
                  "tri_par", "tri_u", "tri_v", "tri_full", "tri_upd", "leaf_refs", "light_samples"]

@@ -241,6 +241,7 @@ struct Hit { /* R/src/Hit.h + the fields of rt_hit */
     float t = INF;
     V3 p, n;
     int type = -1, object = -1, tri = -1;
+    float u = 0.f, v = 0.f; /* barycentrics of a mesh hit (w1, w2 of RayTriangleIntersection) */
 };
 
 /* AABB::intersectRayAABB, R/src/AABB.h:30-73. */
@@ -353,7 +354,7 @@ bool mesh_hit(const OScene& s, const rt_mesh& m, const Ray& r, Hit& h, Counters&
             ++c.tri_upd;
             best = t;
             found = true;
-            h.hit = true; h.t = t; h.tri = (int)i;
+            h.hit = true; h.t = t; h.tri = (int)i; h.u = u; h.v = v;
             h.p = add(r.o, mul(t, r.d));
             V3 nn = add(add(mul(1.0f - u - v, from3(N + 3 * i0)), mul(u, from3(N + 3 * i1))),
                         mul(v, from3(N + 3 * i2)));
@@ -854,8 +855,10 @@ void fill_hit(rt_hit& o, const Hit& h) {
     o.object = h.hit ? h.object : -1;
     o.tri = (h.hit && h.type == RT_MESH) ? h.tri : -1;
     o.t = h.hit ? h.t : FLT_MAX; /* RaySceneIntersection() : t(FLT_MAX), Scene.h:80 */
+    bool mesh = h.hit && h.type == RT_MESH;
+    o.u = mesh ? h.u : 0.f; o.v = mesh ? h.v : 0.f;
     for (int a = 0; a < 3; ++a) { o.p[a] = h.hit ? h.p[a] : 0.f; o.n[a] = h.hit ? h.n[a] : 0.f; }
-    o.pad_ = 0.f;
+    o.pad0_ = o.pad1_ = o.pad2_ = 0.f;
 }
 
 } // namespace

@@ -62,7 +62,8 @@ class Stats(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri", "<i4"), ("t", "<f4"),
-                      ("p", "<f4", 3), ("n", "<f4", 3), ("pad", "<f4")])
+                      ("u", "<f4"), ("v", "<f4"), ("pad0", "<f4"), ("p", "<f4", 3), ("pad1", "<f4"),
+                      ("n", "<f4", 3), ("pad2", "<f4")])
 
 # every symbol include/rtamd.h declares
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_kdtree",

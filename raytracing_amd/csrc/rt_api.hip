@@ -95,23 +95,32 @@ __global__ __launch_bounds__(256) void k_render(DeviceScene sc, DCamera cam, Ren
     flush_counters(counters, cnt, my_samples);
 }
 
+
+RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u, float v) {
+    rt_hit r;
+    r.hit = h.hit ? 1 : 0;
+    r.type = h.hit ? type : -1;
+    r.object = h.hit ? object : -1;
+    r.tri = (h.hit && type == RT_MESH) ? tri : -1;
+    r.t = h.hit ? h.t : 3.402823466e+38f;
+    r.u = (h.hit && type == RT_MESH) ? u : 0.f;
+    r.v = (h.hit && type == RT_MESH) ? v : 0.f;
+    r.pad0_ = r.pad1_ = r.pad2_ = 0.f;
+    r.p[0] = h.p.x; r.p[1] = h.p.y; r.p[2] = h.p.z;
+    r.n[0] = h.n.x; r.n[1] = h.n.y; r.n[2] = h.n.z;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir,
                                                    size_t n, rt_hit* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
-    FullHit h = finish_hit(sc, closest_rec(sc, o, d, cnt), o, d);
-    rt_hit r;
-    r.hit = h.hit ? 1 : 0;
-    r.type = h.hit ? h.type : -1;
-    r.object = h.hit ? h.obj : -1;
-    r.tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)sc.meshes[h.obj].first_tri) : -1;
-    r.t = h.hit ? h.t : 3.402823466e+38f;
-    r.p[0] = h.p.x; r.p[1] = h.p.y; r.p[2] = h.p.z;
-    r.n[0] = h.n.x; r.n[1] = h.n.y; r.n[2] = h.n.z;
-    r.pad_ = 0.f;
-    out[i] = r;
+    HitRec rec = closest_rec(sc, o, d, cnt);
+    FullHit h = finish_hit(sc, rec, o, d);
+    int tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)sc.meshes[h.obj].first_tri) : -1;
+    out[i] = pack_hit(h, h.type, h.obj, tri, rec.u, rec.v);
 }
 
 __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t mesh, const float* __restrict__ org,
@@ -123,16 +132,7 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     const DMesh m = sc.meshes[mesh];
     if (mesh_closest(sc, m, o, d, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
     FullHit h = finish_hit(sc, rec, o, d);
-    rt_hit r;
-    r.hit = h.hit ? 1 : 0;
-    r.type = h.hit ? RT_MESH : -1;
-    r.object = h.hit ? (int)mesh : -1;
-    r.tri = h.hit ? (int)(h.tri - (int)m.first_tri) : -1;
-    r.t = h.hit ? h.t : 3.402823466e+38f;
-    r.p[0] = h.p.x; r.p[1] = h.p.y; r.p[2] = h.p.z;
-    r.n[0] = h.n.x; r.n[1] = h.n.y; r.n[2] = h.n.z;
-    r.pad_ = 0.f;
-    out[i] = r;
+    out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)(h.tri - (int)m.first_tri) : -1, rec.u, rec.v);
 }
 
 __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
@@ -362,7 +362,7 @@ int rt_intersect_device(rt_scene_t scene, const float* d_org, const float* d_dir
     if (n == 0) return RT_OK;
     if (!d_org || !d_dir || !d_out) return fail(RT_E_INVALID, "rt_intersect: null buffer");
     if (n > 0x7fffffffull * 256) return fail(RT_E_LIMIT, "rt_intersect: too many rays for one launch");
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
+    hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
     hipLaunchKernelGGL(k_intersect, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -487,7 +487,7 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     std::string err;
     if (!rtb::invert_camera(*cam, dc, err)) return fail(RT_E_INVALID, err);
     if (rp.n_local_tiles == 0) return RT_OK;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
+    hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
     uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
     hipLaunchKernelGGL(k_render, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, r->dev, dc, rp, d_rgb_tiles, d_counters3);
     HIP_TRY(hipGetLastError());

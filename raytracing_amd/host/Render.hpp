@@ -1,0 +1,44 @@
+/* Render.hpp -- ray_trace_from_camera() of R/main.cpp:170-221 for a headless host: the
+ * per-pixel / per-sample loop runs on the GPU (rt_render), the host keeps the timing print and
+ * the ASCII P3 writer with the reference's quantisation (int)(255.f * min(1.f, c)). */
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+#include "Camera.hpp"
+#include "Scene.hpp"
+
+inline bool write_ppm_p3(const std::string& filename, const std::vector<Vec3>& image, int w, int h) {
+    std::ofstream f(filename.c_str(), std::ios::binary);
+    if (f.fail()) {
+        std::cout << "Could not open file: " << filename << std::endl;
+        return false;
+    }
+    f << "P3" << std::endl << w << " " << h << std::endl << 255 << std::endl;
+    for (int i = 0; i < w * h; ++i)
+        f << (int)(255.f * std::min<float>(1.f, image[i][0])) << " " << (int)(255.f * std::min<float>(1.f, image[i][1])) << " "
+          << (int)(255.f * std::min<float>(1.f, image[i][2])) << " ";
+    f << std::endl;
+    return true;
+}
+
+inline void ray_trace_from_camera(Scene& scene, Camera& camera, unsigned nsamples = 50, uint32_t seed = 1,
+                                  const std::string& filename = "./rendu.ppm", rt_stats* stats_out = nullptr) {
+    int w = camera.getScreenWidth(), h = camera.getScreenHeight();
+    std::cout << "Ray tracing a " << w << " x " << h << " image" << std::endl;
+    auto start = std::chrono::high_resolution_clock::now();
+    camera.apply();
+    std::vector<Vec3> image;
+    rt_stats st{};
+    scene.render(camera.glState(), w, h, nsamples, seed, image, &st);
+    std::cout << "\rProgress: 100% - Done!            " << std::endl;
+    if (!write_ppm_p3(filename, image, w, h)) return;
+    auto end = std::chrono::high_resolution_clock::now();
+    auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count();
+    std::cout << "Image saved to '" << filename << "' in " << ms << " ms." << std::endl;
+    std::cout << st.rays << " rays, kernel " << st.kernel_ms << " ms (" << (st.kernel_ms > 0 ? st.rays / st.kernel_ms / 1e3 : 0.0) << " Mrays/s)" << std::endl;
+    if (stats_out) *stats_out = st;
+}

@@ -36,7 +36,7 @@ def assert_hits_equal(a, b, what):
     for f in ("hit", "type", "object", "tri"):
         bad = np.nonzero(a[f] != b[f])[0]
         assert bad.size == 0, f"{what}: {f} differs on {bad.size} rays, first {bad[:5]}: {a[f][bad[:5]]} vs {b[f][bad[:5]]}"
-    for f in ("t", "p", "n"):
+    for f in ("t", "u", "v", "p", "n"):
         bad = np.nonzero((_bits(a[f]) != _bits(b[f])).reshape(len(a), -1).any(axis=1))[0]
         assert bad.size == 0, f"{what}: {f} bits differ on {bad.size} rays, first {bad[:5]}"
 

@@ -1,0 +1,95 @@
+"""CPU tests of the host side: the product's C++ Scene / Camera classes against the oracle's own
+restatement of the reference's set-up code (two independent implementations, bit-identical data),
+the C-ABI library's exports, and the tile bookkeeping."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracing_amd import api, host
+from tests import descutil
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    header = open(os.path.join(os.path.dirname(api.HERE), "include", "rtamd.h")).read()
+    import re
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(rt_\w+)\(", header, flags=re.M))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_device_calls_fail_loudly_without_init():
+    """No CPU fallback: without rt_init (or without a GPU) every compute entry point returns an error."""
+    L = api.lib()
+    z = np.zeros(3, np.float32)
+    out = np.zeros(1, api.HIT_DTYPE)
+    rc = L.rt_intersect(1, z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p))
+    assert rc in (-2, -4) and L.rt_last_error()
+
+
+@pytest.mark.parametrize("sid", [0, 1, 2, 3])
+def test_host_scene_equals_oracle_scene(sid):
+    so, sh = orc.Scene.builtin(sid), host.HostScene.builtin(sid)  # keep both alive: desc points into them
+    a, b = descutil.describe(so.desc), descutil.describe(sh.desc)
+    for k in a:
+        assert a[k] == b[k], f"scene {sid}: {k} differs"
+
+
+def test_host_scene_mesh_aabb_replay():
+    o = orc.Scene.builtin(3)
+    o.compute_mesh_aabbs()
+    a = descutil.describe(o.desc)
+    sh = host.HostScene.builtin(3, compute_mesh_aabbs=True)
+    b = descutil.describe(sh.desc)
+    assert a["meshes"] == b["meshes"]
+    assert np.isfinite(np.frombuffer(a["meshes"][0][1], np.float32)).all()
+
+
+@pytest.mark.parametrize("wh", [(480, 480), (1920, 1080), (3840, 2160), (100, 37)])
+def test_host_camera_equals_oracle_camera(wh):
+    a, b = orc.camera_default(*wh), host.camera_default(*wh)
+    assert descutil.raw(a) == descutil.raw(b)
+
+
+def test_rotated_camera_equals_oracle_camera():
+    q = np.array([0.1, -0.2, 0.3, 0.9], np.float32)
+    q /= np.float32(np.linalg.norm(q))
+    a = orc.camera_build(60.0, 1.5, 500.0, 640, 360, 0.3, -0.2, -3.1, 2.5, q)
+    b = host.camera_build(60.0, 1.5, 500.0, 640, 360, 0.3, -0.2, -3.1, 2.5, q)
+    assert descutil.raw(a) == descutil.raw(b)
+
+
+def test_tiles_per_rank_partition():
+    for (w, h, tw, th) in [(1920, 1080, 16, 16), (100, 37, 16, 8), (7, 5, 8, 8)]:
+        total = ((w + tw - 1) // tw) * ((h + th - 1) // th)
+        for world in (1, 2, 3, 8):
+            per = [api.tiles_per_rank(w, h, tw, th, r, world) for r in range(world)]
+            assert sum(per) == total and max(per) == per[0] and max(per) - min(per) <= 1
+    assert api.tiles_per_rank(10, 10, 0, 8, 0, 1) == 0 and api.tiles_per_rank(10, 10, 8, 8, 2, 2) == 0
+
+
+def test_tiles_to_image_roundtrip():
+    w, h, tw, th, world = 50, 21, 16, 8, 3
+    img = np.random.default_rng(0).random((h, w, 3)).astype(np.float32)
+    tx, ty = (w + tw - 1) // tw, (h + th - 1) // th
+    per = api.tiles_per_rank(w, h, tw, th, 0, world)
+    buf = np.zeros((world, per, th, tw, 3), np.float32)
+    for t in range(tx * ty):
+        x0, y0 = (t % tx) * tw, (t // tx) * th
+        blk = img[y0:y0 + th, x0:x0 + tw]
+        buf[t % world, t // world, :blk.shape[0], :blk.shape[1]] = blk
+    out = api.tiles_to_image(buf.reshape(world, -1), w, h, tw, th, world)
+    assert np.array_equal(out, img)
+
+
+def test_ppm_writer_matches_reference_format(tmp_path):
+    rgb = np.array([[[0.0, 0.5, 1.0], [2.0, 0.999, 0.00392157]]], np.float32)
+    p = str(tmp_path / "x.ppm")
+    host.write_ppm(p, rgb)
+    toks = open(p).read().split()
+    assert toks[:4] == ["P3", "2", "1", "255"]
+    assert [int(t) for t in toks[4:]] == list(orc.quantize(rgb).ravel())
