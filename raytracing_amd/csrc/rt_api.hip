@@ -50,7 +50,8 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_render(DeviceScene sc, DCamera cam, RenderParams rp, float* __restrict__ out,
+template <bool KD>
+__global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(256) void k_render(DeviceScene sc, DCamera cam, Ren
             float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
-            primary_ray(cam, u, v, o, d);
-            col = trace_path(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
+            primary_ray(cam, u, v, &o, &d);
+            col = trace_path<KD>(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
             ++my_samples;
         }
         /* image[x + y*w] += color, one sample after the other */
@@ -111,13 +112,14 @@ RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u,
     return r;
 }
 
+template <bool KD>
 __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir,
                                                    size_t n, rt_hit* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
-    HitRec rec = closest_rec(sc, o, d, cnt);
+    HitRec rec = closest_rec<KD>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
     int tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)sc.meshes[h.obj].first_tri) : -1;
     out[i] = pack_hit(h, h.type, h.obj, tri, rec.u, rec.v);
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)(h.tri - (int)m.first_tri) : -1, rec.u, rec.v);
 }
 
+template <bool KD>
 __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
                                                const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __re
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
         Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
-        f3 c = trace_path(sc, o, d, rng, cnt);
+        f3 c = trace_path<KD>(sc, o, d, rng, cnt);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
         smp = 1;
     }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __re
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 o, d;
-    primary_ray(cam, u[i], v[i], o, d);
+    primary_ray_inl(cam, u[i], v[i], o, d);
     org[3 * i] = o.x; org[3 * i + 1] = o.y; org[3 * i + 2] = o.z;
     dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
 }
@@ -173,11 +176,17 @@ struct SceneRes {
     std::vector<void*> allocs;
 };
 
+const unsigned kCamSlots = 64;
+
 struct Lib {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    /* inverted cameras of the renders in flight: a ring in device memory, one slot per rt_render call
+     * (the kernel reads its camera through a pointer so the 2 x 16 doubles never occupy registers) */
+    DCamera* cam_ring = nullptr;
+    unsigned cam_next = 0;
     std::map<rt_scene_t, SceneRes*> scenes;
     rt_scene_t next_handle = 1;
     std::string error;
@@ -270,6 +279,8 @@ int rt_init(int device) {
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(hipMalloc((void**)&g.cam_ring, kCamSlots * sizeof(DCamera)));
+    g.cam_next = 0;
     g.device = device;
     g.ready = true;
     return RT_OK;
@@ -281,6 +292,8 @@ int rt_shutdown(void) {
     (void)hipStreamSynchronize(g.stream);
     for (auto& kv : g.scenes) release(kv.second);
     g.scenes.clear();
+    (void)hipFree(g.cam_ring);
+    g.cam_ring = nullptr;
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
@@ -363,7 +376,8 @@ int rt_intersect_device(rt_scene_t scene, const float* d_org, const float* d_dir
     if (!d_org || !d_dir || !d_out) return fail(RT_E_INVALID, "rt_intersect: null buffer");
     if (n > 0x7fffffffull * 256) return fail(RT_E_LIMIT, "rt_intersect: too many rays for one launch");
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
-    hipLaunchKernelGGL(k_intersect, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
+    if (r->dev.root_is_leaf) hipLaunchKernelGGL(k_intersect<false>, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
+    else hipLaunchKernelGGL(k_intersect<true>, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -452,8 +466,12 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
     HIP_TRY(hipMemcpyAsync(d_s, sample, 4 * n, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, g.stream));
     HIP_TRY(hipEventRecord(g.ev0, g.stream));
-    hipLaunchKernelGGL(k_trace, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
-                       (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
+    if (r->dev.root_is_leaf)
+        hipLaunchKernelGGL(k_trace<false>, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
+                           (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
+    else
+        hipLaunchKernelGGL(k_trace<true>, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
+                           (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
@@ -489,7 +507,11 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     if (rp.n_local_tiles == 0) return RT_OK;
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
     uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
-    hipLaunchKernelGGL(k_render, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, r->dev, dc, rp, d_rgb_tiles, d_counters3);
+    DCamera* d_cam = g.cam_ring + (g.cam_next++ % kCamSlots);
+    HIP_TRY(hipMemcpyAsync(d_cam, &dc, sizeof(DCamera), hipMemcpyHostToDevice, st)); /* pageable source: staged before the call returns */
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (r->dev.root_is_leaf) hipLaunchKernelGGL(k_render<false>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters3);
+    else hipLaunchKernelGGL(k_render<true>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters3);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

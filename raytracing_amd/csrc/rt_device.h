@@ -233,13 +233,14 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
 }
 
 /* ---- Scene::computeIntersection, R/src/Scene.h:169-205 via KDTree::intersect :679-687 ----- */
+template <bool KD>
 RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
     ++cnt.rays;
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     float t_in, t_out;
     if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-    if (sc.root_is_leaf) leaf_closest(sc, 0, (int)sc.n_refs, o, d, best);
+    if (!KD) leaf_closest(sc, 0, (int)sc.n_refs, o, d, best); /* the root is a leaf: every built-in scene */
     else kd_closest(sc, o, d, t_in, t_out, best);
     return best;
 }
@@ -262,11 +263,12 @@ RT_DEV FullHit finish_hit(const DeviceScene& sc, const HitRec& r, f3 o, f3 d) {
 }
 
 /* shadow test of Scene::phong, R/src/Scene.h:379-384: closest hit exists and t < dist */
+template <bool KD>
 RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
     ++cnt.rays;
     float t_in, t_out;
     if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return false;
-    if (sc.root_is_leaf) return leaf_any(sc, 0, (int)sc.n_refs, o, d, dist);
+    if (!KD) return leaf_any(sc, 0, (int)sc.n_refs, o, d, dist);
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     return kd_closest(sc, o, d, t_in, t_out, best) && best.type >= 0 && best.t < dist;
@@ -281,10 +283,11 @@ struct Rng {
 
 /* powf(x, y) for x >= 0 through double: x^16 (the Cornell shininess) by four exact-enough double
  * squarings, anything else through the double pow; rounded once to float. */
+__device__ __attribute__((noinline)) float pow_general(float x, float y) { return (float)pow((double)x, (double)y); }
 RT_DEV float pow_shiny(float x, float y) {
     if (y == 16.0f) { double a = (double)x; a *= a; a *= a; a *= a; a *= a; return (float)a; }
     if (y == 0.0f) return 1.0f;
-    return (float)pow((double)x, (double)y);
+    return pow_general(x, y); /* kept out of line: the double pow is large and rarely runs */
 }
 
 /* Scene::computeLightContribution, R/src/Scene.h:304-316 */
@@ -302,6 +305,7 @@ RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
 }
 
 /* ---- Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276) ------------------ */
+template <bool KD>
 RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     ++cnt.nodes;
     const DMaterial m = sc.materials[material_index(sc, h.type, h.obj)];
@@ -323,7 +327,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                 f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                 f3 SP = S - P;
                 f3 L = norm3(SP);
-                if (occluded(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
+                if (occluded<KD>(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
                 light_term(sum, lt, m, N, V, L);
             }
             sum = sum / 16.f;
@@ -332,7 +336,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
         } else {
             f3 SP = ld3(lt.pos) - P;
             f3 L = norm3(SP);
-            if (occluded(sc, so, norm3(L), len3(SP), cnt)) continue;
+            if (occluded<KD>(sc, so, norm3(L), len3(SP), cnt)) continue;
             light_term(diffuse, lt, m, N, V, L);
         }
     }
@@ -349,17 +353,18 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
  *   kind 3 glass, reflected child running, no refracted ray (total internal reflection)
  *   kind 4 glass, refracted child running : a = reflected colour */
 #define RT_MAX_BOUNCES 10
+template <bool KD>
 RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
     float stk[RT_MAX_BOUNCES][8];
     int sp = 0;
     f3 ret = mk3(0.f, 0.f, 0.f);
     for (;;) {
-        HitRec rec = closest_rec(sc, o, d, cnt);
+        HitRec rec = closest_rec<KD>(sc, o, d, cnt);
         bool descended = false;
         if (rec.type < 0) ret = mk3(0.f, 0.f, 0.f);
         else {
             FullHit h = finish_hit(sc, rec, o, d);
-            f3 col = shade(sc, h, rng, cnt);
+            f3 col = shade<KD>(sc, h, rng, cnt);
             ret = col;
             if (sp < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
                 const DMaterial m = sc.materials[sc.spheres[h.obj].mat];
@@ -425,7 +430,7 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
 
 /* ---- screen_space_to_world_space_ray, R/src/matrixUtilities.h:198-222 --------------------
  * double arithmetic exactly as the reference; the direction comes back normalised once. */
-RT_DEV void primary_ray(const DCamera& cam, float u, float v, f3& o, f3& d) {
+RT_DEV void primary_ray_inl(const DCamera& cam, float u, float v, f3& o, f3& d) {
     double x = (double)2.f * (double)u - (double)1.f;
     double y = -((double)2.f * (double)v - (double)1.f);
     double z = cam.depth_near, w = 1.0;
@@ -442,6 +447,12 @@ RT_DEV void primary_ray(const DCamera& cam, float u, float v, f3& o, f3& d) {
     f3 world = mk3((float)(b0 / b3), (float)(b1 / b3), (float)(b2 / b3));
     o = ld3(cam.eye);
     d = norm3(world - o);
+}
+
+/* out-of-line form for the render kernel: keeps the 2 x 16 doubles out of the registers that stay
+ * live while the path is traced */
+__device__ __attribute__((noinline)) void primary_ray(const DCamera* cam, float u, float v, f3* o, f3* d) {
+    primary_ray_inl(*cam, u, v, *o, *d);
 }
 
 #endif /* RT_DEVICE_H */
