@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* 
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
     HitRec rec = closest_rec<KD>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
-    int tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)sc.meshes[h.obj].first_tri) : -1;
+    int tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)ldc(&sc.meshes[h.obj].first_tri)) : -1;
     out[i] = pack_hit(h, h.type, h.obj, tri, rec.u, rec.v);
 }
 
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     if (i >= n) return;
     f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
     HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
-    const DMesh m = sc.meshes[mesh];
+    const DMesh m = ldc(&sc.meshes[mesh]);
     if (mesh_closest(sc, m, o, d, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
     FullHit h = finish_hit(sc, rec, o, d);
     out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)(h.tri - (int)m.first_tri) : -1, rec.u, rec.v);

@@ -25,6 +25,10 @@ struct f3 { float x, y, z; };
 
 RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+RT_DEV f3 ld3c(const float* p) { /* same through the constant address space (scene tables) */
+    const __attribute__((address_space(4))) float* q = (const __attribute__((address_space(4))) float*)p;
+    return mk3(q[0], q[1], q[2]);
+}
 RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
@@ -38,6 +42,20 @@ RT_DEV float max_std(float a, float b) { return (a < b) ? b : a; } /* std::max, 
 RT_DEV float min_std(float a, float b) { return (b < a) ? b : a; } /* std::min */
 
 #define RT_INF __builtin_inff()
+
+/* Scene tables never change while a kernel runs.  Reading them through the constant address space
+ * tells the compiler so: a load whose address is wave-uniform then becomes a scalar load (s_load
+ * into SGPRs through the scalar cache) instead of 64 identical vector loads; a divergent address
+ * still gets an ordinary vector load. */
+template <class T>
+RT_DEV T ldc(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "scene records are dword multiples");
+    const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)p;
+    union { T v; uint32_t w[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) u.w[i] = q[i]; /* merged into dwordx4 / x8 loads */
+    return u.v;
+}
 
 /* per-lane work counters; summed over the wave and added to global memory once per wave */
 struct Cnt { uint32_t rays, nodes; };
@@ -138,7 +156,7 @@ RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
     best_t = 3.402823466e+38f; /* FLT_MAX */
     for (uint32_t i = 0; i < m.n_tris; ++i) {
         float t, u, v;
-        if (tri_t(sc.tris[m.first_tri + i], o, d, t, u, v) && t > 1e-6f && t < best_t) {
+        if (tri_t(ldc(&sc.tris[m.first_tri + i]), o, d, t, u, v) && t > 1e-6f && t < best_t) {
             best_t = t; best_tri = (int)(m.first_tri + i); best_u = u; best_v = v; found = true;
         }
     }
@@ -147,7 +165,7 @@ RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
 RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist) {
     for (uint32_t i = 0; i < m.n_tris; ++i) {
         float t, u, v;
-        if (tri_t(sc.tris[m.first_tri + i], o, d, t, u, v) && t > 1e-6f && t < dist) return true;
+        if (tri_t(ldc(&sc.tris[m.first_tri + i]), o, d, t, u, v) && t > 1e-6f && t < dist) return true;
     }
     return false;
 }
@@ -156,13 +174,13 @@ RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
 RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, HitRec& best) {
     bool any = false;
     for (int r = first; r < first + count; ++r) {
-        DRef ref = sc.refs[r];
+        DRef ref = ldc(&sc.refs[r]);
         float t = 0.f, u = 0.f, v = 0.f;
         int tri = -1;
         bool ok;
-        if (ref.type == RT_SPHERE) ok = sphere_t(sc.spheres[ref.object], o, d, t);
-        else if (ref.type == RT_SQUARE) ok = square_t(sc.squares[ref.object], o, d, t);
-        else ok = mesh_closest(sc, sc.meshes[ref.object], o, d, t, tri, u, v);
+        if (ref.type == RT_SPHERE) ok = sphere_t(ldc(&sc.spheres[ref.object]), o, d, t);
+        else if (ref.type == RT_SQUARE) ok = square_t(ldc(&sc.squares[ref.object]), o, d, t);
+        else ok = mesh_closest(sc, ldc(&sc.meshes[ref.object]), o, d, t, tri, u, v);
         if (ok) {
             any = true;
             if (best.type < 0 || t < best.t) { best.t = t; best.type = ref.type; best.obj = ref.object; best.tri = tri; best.u = u; best.v = v; }
@@ -173,11 +191,11 @@ RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d
 /* shadow query on a leaf: "closest hit exists and its t < dist" == "some object reports t < dist" */
 RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist) {
     for (int r = first; r < first + count; ++r) {
-        DRef ref = sc.refs[r];
+        DRef ref = ldc(&sc.refs[r]);
         float t;
-        if (ref.type == RT_SPHERE) { if (sphere_t(sc.spheres[ref.object], o, d, t) && t < dist) return true; }
-        else if (ref.type == RT_SQUARE) { if (square_t(sc.squares[ref.object], o, d, t) && t < dist) return true; }
-        else { if (mesh_any(sc, sc.meshes[ref.object], o, d, dist)) return true; }
+        if (ref.type == RT_SPHERE) { if (sphere_t(ldc(&sc.spheres[ref.object]), o, d, t) && t < dist) return true; }
+        else if (ref.type == RT_SQUARE) { if (square_t(ldc(&sc.squares[ref.object]), o, d, t) && t < dist) return true; }
+        else { if (mesh_any(sc, ldc(&sc.meshes[ref.object]), o, d, dist)) return true; }
     }
     return false;
 }
@@ -196,7 +214,7 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
     bool ret = false;
     for (;;) {
         for (;;) { /* descend until a leaf */
-            DKdNode nd = sc.kd[node];
+            DKdNode nd = ldc(&sc.kd[node]);
             if (nd.leaf) { ret = leaf_closest(sc, nd.first_ref, nd.n_refs, o, d, best); break; }
             float da = comp(d, nd.axis), oa = comp(o, nd.axis);
             float t_split = (__builtin_fabsf(da) < sc.kd_epsilon) ? RT_INF : (nd.cut - oa) / da;
@@ -252,11 +270,11 @@ RT_DEV FullHit finish_hit(const DeviceScene& sc, const HitRec& r, f3 o, f3 d) {
     h.p = mk3(0.f, 0.f, 0.f); h.n = mk3(0.f, 0.f, 0.f);
     if (!h.hit) return h;
     h.p = o + r.t * d;
-    if (r.type == RT_SPHERE) h.n = norm3(h.p - ld3(sc.spheres[r.obj].c));                  /* Sphere.h:120-122 */
-    else if (r.type == RT_SQUARE) h.n = ld3(sc.squares[r.obj].nn);                         /* Square.h:108-109 */
+    if (r.type == RT_SPHERE) h.n = norm3(h.p - ld3c(sc.spheres[r.obj].c));                  /* Sphere.h:120-122 */
+    else if (r.type == RT_SQUARE) h.n = ld3c(sc.squares[r.obj].nn);                         /* Square.h:108-109 */
     else {                                                                                  /* Mesh.h:267-272 */
-        DTri tr = sc.tris[r.tri];
-        f3 n0 = ld3(sc.normals + 3 * (size_t)tr.i0), n1 = ld3(sc.normals + 3 * (size_t)tr.i1), n2 = ld3(sc.normals + 3 * (size_t)tr.i2);
+        DTri tr = ldc(&sc.tris[r.tri]);
+        f3 n0 = ld3c(sc.normals + 3 * (size_t)tr.i0), n1 = ld3c(sc.normals + 3 * (size_t)tr.i1), n2 = ld3c(sc.normals + 3 * (size_t)tr.i2);
         h.n = norm3(((1.0f - r.u - r.v) * n0 + r.u * n1) + r.v * n2);
     }
     return h;
@@ -301,14 +319,14 @@ RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V
 }
 
 RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
-    return type == RT_SPHERE ? sc.spheres[obj].mat : (type == RT_SQUARE ? sc.squares[obj].mat : sc.meshes[obj].mat);
+    return type == RT_SPHERE ? ldc(&sc.spheres[obj].mat) : (type == RT_SQUARE ? ldc(&sc.squares[obj].mat) : ldc(&sc.meshes[obj].mat));
 }
 
 /* ---- Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276) ------------------ */
 template <bool KD>
 RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     ++cnt.nodes;
-    const DMaterial m = sc.materials[material_index(sc, h.type, h.obj)];
+    const DMaterial m = ldc(&sc.materials[material_index(sc, h.type, h.obj)]);
     f3 ambient = 0.35f * mk3(0.2f, 0.2f, 0.2f);
     f3 diffuse = mk3(0.f, 0.f, 0.f), specular = mk3(0.f, 0.f, 0.f);
     const f3 P = h.p;
@@ -316,7 +334,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     const f3 V = norm3(-1.f * P);              /* camera assumed at the world origin */
     const f3 so = P + 0.001f * N;              /* shadow-ray origin */
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
-        const DLight lt = sc.lights[li];
+        const DLight lt = ldc(&sc.lights[li]);
         if (lt.type == RT_LIGHT_QUAD) {
             f3 sum = mk3(0.f, 0.f, 0.f);
             f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
@@ -367,7 +385,7 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
             f3 col = shade<KD>(sc, h, rng, cnt);
             ret = col;
             if (sp < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
-                const DMaterial m = sc.materials[sc.spheres[h.obj].mat];
+                const DMaterial m = ldc(&sc.materials[ldc(&sc.spheres[h.obj].mat)]);
                 f3 P = h.p, N = h.n, I = d;
                 if (m.type == RT_MAT_MIRROR) {
                     f3 R = I - (2.0f * dot3(I, N)) * N;
