@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librtamd.so")
+LIB_PATH = os.environ.get("RTAMD_LIB", os.path.join(HERE, "csrc", "librtamd.so"))  # RTAMD_LIB: A/B builds
 
 RT_MESH, RT_SPHERE, RT_SQUARE = 0, 1, 2
 RT_MAT_DIFFUSE, RT_MAT_GLASS, RT_MAT_MIRROR = 0, 1, 2

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 
 namespace rtb {
@@ -94,6 +95,30 @@ int32_t build_node(const rt_scene_desc& d, Built& out, const Box& box, int32_t f
 
 bool fail(std::string& err, const char* what) { err = what; return false; }
 
+/* smallest positive float x (possibly +inf) for which pred(x) holds; pred must be monotonic */
+template <class Pred>
+float first_float_where(Pred pred) {
+    uint32_t lo = 1, hi = 0x7f800000u; /* smallest subnormal .. +inf, ordered like the floats */
+    auto as_float = [](uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; };
+    if (!pred(as_float(hi))) return std::numeric_limits<float>::quiet_NaN(); /* nothing passes */
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (pred(as_float(mid))) hi = mid; else lo = mid + 1;
+    }
+    return as_float(lo);
+}
+/* interval [lo, hi) of x = dot(P - v0, edge) that the reference's `0 < x/len && x/len < len` accepts */
+void edge_interval(float len, float& lo, float& hi) {
+    lo = std::numeric_limits<float>::infinity(); hi = 0.f; /* empty */
+    if (!(len > 0.f) || std::isinf(len)) return;
+    volatile float L = len; /* keep the real division: no reciprocal tricks by the host compiler */
+    float a = first_float_where([&](float x) { return x / L > 0.f; });
+    float b = first_float_where([&](float x) { return x / L >= L; });
+    if (std::isnan(a)) return;
+    lo = a;
+    hi = std::isnan(b) ? std::numeric_limits<float>::infinity() : b;
+}
+
 }  // namespace
 
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
@@ -128,7 +153,8 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
         DSquare o{};
         F3 v0 = ld(q.v[0]), w = ld(q.v[1]) - v0, h = ld(q.v[3]) - v0, n = cross(w, h);
         st(o.v0, v0); st(o.w, w); st(o.h, h); st(o.n, n);
-        o.width = len(w); o.height = len(h);
+        edge_interval(len(w), o.w_lo, o.w_hi);
+        edge_interval(len(h), o.h_lo, o.h_hi);
         float L = len(n);
         o.nn[0] = n.x / L; o.nn[1] = n.y / L; o.nn[2] = n.z / L;
         o.mat = q.material;

@@ -96,6 +96,16 @@ RT_DEV bool box_test(const float lo[3], const float hi[3], f3 o, f3 d, float& t_
     return t_out >= 0.0f;
 }
 
+/* A ray that starts inside the root box (faces included) always passes AABB::intersectRayAABB:
+ * on an axis with |d| >= 1e-8 the numerators (lo - o) <= 0 <= (hi - o) are exact, so the two
+ * quotients have opposite signs (or are zero), t_entry stays <= 0 and t_exit >= 0, `t_entry >
+ * t_exit` never holds and the final `t_exit >= 0` does (-0 >= 0 is true); on an axis with
+ * |d| < 1e-8 the origin is within the slab.  Checking the origin replaces the six divisions for
+ * every shadow and bounce ray. */
+RT_DEV bool inside_box(const float lo[3], const float hi[3], f3 o) {
+    return o.x >= lo[0] && o.x <= hi[0] && o.y >= lo[1] && o.y <= hi[1] && o.z >= lo[2] && o.z <= hi[2];
+}
+
 /* ---- Sphere::intersect, R/src/Sphere.h:85-162: distance only ---------------------------- */
 RT_DEV bool sphere_t(const DSphere& s, f3 o, f3 d, float& t) {
     f3 oc = o - ld3(s.c);
@@ -121,15 +131,17 @@ RT_DEV bool sphere_t(const DSphere& s, f3 o, f3 d, float& t) {
     return false;
 }
 
-/* ---- Square::intersect, R/src/Square.h:63-115: distance only ---------------------------- */
+/* ---- Square::intersect, R/src/Square.h:63-115: distance only ----------------------------
+ * The two `0 < x / len && x / len < len` checks are evaluated as interval tests on x (bounds made
+ * exact on the host, see DSquare). */
+RT_DEV bool square_in_rect(const DSquare& q, f3 bp) {
+    float x = dot3(bp, ld3(q.w)), y = dot3(bp, ld3(q.h));
+    return x >= q.w_lo && x < q.w_hi && y >= q.h_lo && y < q.h_hi;
+}
 RT_DEV bool square_t(const DSquare& q, f3 o, f3 d, float& t) {
     f3 v0 = ld3(q.v0), n = ld3(q.n);
     float tt = dot3(v0 - o, n) / dot3(d, n);
-    if (tt >= 0.f) {
-        f3 bp = (o + tt * d) - v0;
-        float pw = dot3(bp, ld3(q.w)) / q.width, ph = dot3(bp, ld3(q.h)) / q.height;
-        if (0.f < pw && pw < q.width && 0.f < ph && ph < q.height) { t = tt; return true; }
-    }
+    if (tt >= 0.f && square_in_rect(q, (o + tt * d) - v0)) { t = tt; return true; }
     return false; /* t < 0, rectangle missed, or t is NaN (undefined in the reference) */
 }
 
@@ -257,9 +269,14 @@ RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     float t_in, t_out;
-    if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-    if (!KD) leaf_closest(sc, 0, (int)sc.n_refs, o, d, best); /* the root is a leaf: every built-in scene */
-    else kd_closest(sc, o, d, t_in, t_out, best);
+    if (sc.n_kd == 0) return best;
+    if (!KD) { /* the root is a leaf (every built-in scene): only pass / fail of the box matters */
+        if (!inside_box(sc.box_lo, sc.box_hi, o) && !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
+        leaf_closest(sc, 0, (int)sc.n_refs, o, d, best);
+    } else {
+        if (!box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
+        kd_closest(sc, o, d, t_in, t_out, best);
+    }
     return best;
 }
 
@@ -290,6 +307,86 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     return kd_closest(sc, o, d, t_in, t_out, best) && best.type >= 0 && best.t < dist;
+}
+
+/* Shadow queries of one shaded point, RT_SB at a time (root-leaf scenes).  All rays of a batch leave the
+ * same origin, so everything that depends on (origin, object) only -- the sphere's o - c and
+ * |o - c|^2 - r^2, the square's dot(v0 - o, n), a triangle's o - v0 and cross(o - v0, e1) -- is
+ * computed once per object and reused by every direction of the batch, each object record is fetched
+ * once per batch, and the independent dependency chains give the scheduler work to interleave.
+ * Every value is still produced by the reference's operations in the reference's order; the
+ * answer per ray is "the closest hit exists and its t < dist", i.e. some object reports t < dist. */
+#ifndef RT_SB
+#define RT_SB 2
+#endif
+RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[RT_SB], const float dist[RT_SB], bool occ[RT_SB], Cnt& cnt) {
+    bool act[RT_SB];
+    cnt.rays += RT_SB;
+#pragma unroll
+    for (int j = 0; j < RT_SB; ++j) {
+        float t_in, t_out;
+        act[j] = o_inside || box_test(sc.box_lo, sc.box_hi, o, d[j], t_in, t_out);
+        occ[j] = false;
+    }
+    for (int r = 0; r < (int)sc.n_refs; ++r) {
+        DRef ref = ldc(&sc.refs[r]);
+        if (ref.type == RT_SPHERE) {
+            const DSphere s = ldc(&sc.spheres[ref.object]);
+            f3 oc = o - ld3(s.c);
+            float n = len3(oc);
+            float c = (n * n) - s.r2;
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j) {
+                float a = dot3(d[j], d[j]);
+                float b = dot3(2.f * d[j], oc);
+                float delta = b * b - 4.f * a * c;
+                float t = RT_INF; /* stays +inf (never < dist) when the sphere is missed */
+                if (delta > 0.f) {
+                    float sq = __builtin_sqrtf(delta);
+                    float a2 = 2.f * a;
+                    float t1 = (-b - sq) / a2, t2 = (-b + sq) / a2;
+                    if (t1 > 0.f && t2 > 0.f) t = min_std(t1, t2);
+                    else if (t1 > 0.f) t = t1;
+                    else if (t2 > 0.f) t = t2;
+                } else if (delta == 0.f) {
+                    float t0 = -b / (2.f * a);
+                    if (t0 > 0.f) t = t0;
+                }
+                occ[j] = occ[j] || (t < dist[j]);
+            }
+        } else if (ref.type == RT_SQUARE) {
+            const DSquare q = ldc(&sc.squares[ref.object]);
+            f3 v0 = ld3(q.v0), n = ld3(q.n);
+            float num = dot3(v0 - o, n);
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j) {
+                float tt = num / dot3(d[j], n);
+                if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
+            }
+        } else {
+            const DMesh m = ldc(&sc.meshes[ref.object]);
+            for (uint32_t i = 0; i < m.n_tris; ++i) {
+                const DTri tr = ldc(&sc.tris[m.first_tri + i]);
+                f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+                f3 sv = o - ld3(tr.v0);
+                f3 qv = cross3(sv, e1);
+                float e2q = dot3(e2, qv);
+#pragma unroll
+                for (int j = 0; j < RT_SB; ++j) {
+                    f3 h = cross3(d[j], e2);
+                    float a = dot3(e1, h);
+                    float f = 1.0f / a;
+                    float u = f * dot3(sv, h);
+                    float v = f * dot3(d[j], qv);
+                    float t = f * e2q;
+                    bool ok = !(__builtin_fabsf(a) < 1e-6f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && t > 1e-6f && t < dist[j];
+                    occ[j] = occ[j] || ok;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RT_SB; ++j) occ[j] = occ[j] && act[j];
 }
 
 /* ---- random numbers ---------------------------------------------------------------------- */
@@ -338,16 +435,39 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
         if (lt.type == RT_LIGHT_QUAD) {
             f3 sum = mk3(0.f, 0.f, 0.f);
             f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
-            for (int i = 0; i < 16; ++i) {
-                float u = rng.unit();
-                float v = rng.unit();
-                if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
-                f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
-                f3 SP = S - P;
-                f3 L = norm3(SP);
-                if (occluded<KD>(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
-                light_term(sum, lt, m, N, V, L);
-            }
+            if (!KD) {
+                const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
+                for (int i0 = 0; i0 < 16; i0 += RT_SB) {
+                    f3 L[RT_SB], Ld[RT_SB];
+                    float dist[RT_SB];
+                    bool occ[RT_SB];
+#pragma unroll
+                    for (int j = 0; j < RT_SB; ++j) {
+                        float u = rng.unit();
+                        float v = rng.unit();
+                        if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+                        f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
+                        f3 SP = S - P;
+                        L[j] = norm3(SP);
+                        Ld[j] = norm3(L[j]); /* Ray() normalises L again */
+                        dist[j] = len3(SP);
+                    }
+                    shadow_batch(sc, so, so_inside, Ld, dist, occ, cnt);
+#pragma unroll
+                    for (int j = 0; j < RT_SB; ++j)
+                        if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
+                }
+            } else
+                for (int i = 0; i < 16; ++i) {
+                    float u = rng.unit();
+                    float v = rng.unit();
+                    if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+                    f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
+                    f3 SP = S - P;
+                    f3 L = norm3(SP);
+                    if (occluded<KD>(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
+                    light_term(sum, lt, m, N, V, L);
+                }
             sum = sum / 16.f;
             diffuse = diffuse + sum;
             specular = specular + sum; /* the reference adds the quad-light term to both sums */

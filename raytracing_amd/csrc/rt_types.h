@@ -5,8 +5,8 @@
  * Everything a ray needs that does not depend on the ray is computed once on the host with the
  * same binary32 operations the reference evaluates per ray (host code is built with
  * -ffp-contract=off), so reading it back is bit-identical to recomputing it:
- *   square: edge vectors, their cross product, its normalisation, the two edge lengths
- *           (R/src/Square.h:80-84, 98-99, 108-109)
+ *   square: edge vectors, their cross product, its normalisation, and the rectangle test turned
+ *           into interval bounds (R/src/Square.h:80-84, 98-104, 108-109)
  *   sphere: radius * radius (R/src/Sphere.h:104)
  *   triangle: the three vertices scaled by 1.000001f and the two edges (R/src/Mesh.h:220-234)
  * Records are 16-byte multiples so a wave-uniform record is fetched with scalar dwordx4 loads.
@@ -22,12 +22,19 @@ struct DSphere {  /* 32 B */
 };
 
 struct DSquare {  /* 80 B */
-    float v0[3]; float width;
-    float w[3]; float height;
+    float v0[3]; float w_lo;  /* rectangle test along w: w_lo <= dot(P - v0, w) < w_hi, see below */
+    float w[3]; float w_hi;
     float h[3]; int32_t mat;
-    float n[3]; float pad0;   /* cross(w, h), not normalised */
-    float nn[3]; float pad1;  /* normalize(n) */
+    float n[3]; float h_lo;   /* n = cross(w, h), not normalised */
+    float nn[3]; float h_hi;  /* nn = normalize(n) */
 };
+/* The reference accepts a plane hit when 0 < x / |w| && x / |w| < |w| with x = dot(P - v0, w)
+ * (R/src/Square.h:101-104; same along h).  A correctly rounded division by a positive constant is
+ * monotonic in x, so each pair of comparisons is an interval test on x itself: w_lo is the
+ * smallest float x with fl(x / |w|) > 0 and w_hi the smallest float x with fl(x / |w|) >= |w|.
+ * The host finds both by bisection over the float bit patterns using the real division, which
+ * makes the interval test exact and removes two divisions per candidate hit.  A degenerate edge
+ * (|w| zero, infinite or NaN) can never pass the reference's test; it gets the empty interval. */
 
 struct DMaterial {  /* 48 B */
     float kd[3]; float shininess;
