@@ -84,7 +84,7 @@ def main():
     tile_floats = tw * th * 3
     mine = torch.zeros(per_rank * tile_floats, dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(mine) for _ in range(world)] if (rank == 0 and world > 1) else None
-    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    counters = torch.zeros(api.COUNTER_SLOTS, api.COUNTER_STRIDE, dtype=torch.int64, device=dev)
     image = torch.zeros(h * w * 3, dtype=torch.float32, device=dev) if rank == 0 else None
 
     # scatter map tile-major -> row-major for rank 0 (built once, lives in HBM)
@@ -131,7 +131,8 @@ def main():
     dt = time.perf_counter() - t0
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    stats = torch.tensor([float(counters[0].item()), float(counters[1].item()), dt, kernel_ms], dtype=torch.float64, device=dev)
+    totals = counters.sum(0)
+    stats = torch.tensor([float(totals[0].item()), float(totals[1].item()), dt, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -141,6 +141,14 @@ typedef struct rt_stats {
     double kernel_ms;     /* device time of the render kernels (HIP events on the stream)   */
 } rt_stats;
 
+/* Work counters on the device: RT_COUNTER_SLOTS slots of RT_COUNTER_STRIDE uint64 each
+ * ({rays, samples, nodes, 0...}); a workgroup adds into slot (workgroup id % RT_COUNTER_SLOTS), so the
+ * atomics of a launch spread over many cache lines instead of serialising on one.  The totals are
+ * the sums over the slots (rt_counters_total).  The caller zeroes the buffer. */
+#define RT_COUNTER_SLOTS 1024
+#define RT_COUNTER_STRIDE 8
+#define RT_COUNTER_WORDS (RT_COUNTER_SLOTS * RT_COUNTER_STRIDE)
+
 typedef uint64_t rt_scene_t;
 
 /* ---- shared counter-based RNG -------------------------------------------------------------
@@ -221,7 +229,10 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
               float* rgb_tiles, rt_stats* stats);
 int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp,
                      uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
-                     uint32_t world, float* d_rgb_tiles, uint64_t* d_counters3, void* hip_stream);
+                     uint32_t world, float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
+/* d_counters: NULL, or a zeroed device buffer of RT_COUNTER_WORDS uint64 (see above).  Host helper:
+ * totals {rays, samples, nodes} of a counter buffer copied back to the host. */
+void rt_counters_total(const uint64_t* h_counters, uint64_t out3[3]);
 
 /* Scatter `world` gathered tile buffers (rank-major, each padded to max_tiles_per_rank tiles)
  * into a row-major w*h*3 image.  Host helper for the gather step. */

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("RTAMD_LIB", os.path.join(HERE, "csrc", "librtamd.so")
 RT_MESH, RT_SPHERE, RT_SQUARE = 0, 1, 2
 RT_MAT_DIFFUSE, RT_MAT_GLASS, RT_MAT_MIRROR = 0, 1, 2
 RT_LIGHT_SPHERICAL, RT_LIGHT_QUAD = 0, 1
+COUNTER_SLOTS, COUNTER_STRIDE = 1024, 8  # RT_COUNTER_SLOTS / RT_COUNTER_STRIDE of include/rtamd.h
 
 
 class RtError(RuntimeError):
@@ -68,7 +69,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
 # every symbol include/rtamd.h declares
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
-           "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_tiles_to_image"]
+           "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_tiles_to_image", "rt_counters_total"]
 
 _lib = None
 

@@ -40,13 +40,23 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+/* one set of atomics per workgroup, into the workgroup's slot (see RT_COUNTER_SLOTS): a single
+ * shared address would serialise ~6 M atomics per frame at ~12 ns each */
 RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     if (!counters) return;
+    __shared__ uint32_t part[3];
+    if (threadIdx.x < 3) part[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t rays = wave_sum(c.rays), nodes = wave_sum(c.nodes), smp = wave_sum(samples);
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long*)&counters[0], (unsigned long long)rays);
-        atomicAdd((unsigned long long*)&counters[1], (unsigned long long)smp);
-        atomicAdd((unsigned long long*)&counters[2], (unsigned long long)nodes);
+        atomicAdd(&part[0], rays);
+        atomicAdd(&part[1], smp);
+        atomicAdd(&part[2], nodes);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint64_t* slot = counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_STRIDE;
+        atomicAdd((unsigned long long*)&slot[threadIdx.x], (unsigned long long)part[threadIdx.x]);
     }
 }
 
@@ -57,20 +67,17 @@ __global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* _
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
     const uint32_t local_tile = wave / px_per_tile;
-    if (local_tile >= rp.n_local_tiles) return; /* whole wave leaves together */
+    const bool wave_has_pixel = local_tile < rp.n_local_tiles; /* wave-uniform */
     const uint32_t in_tile = wave - local_tile * px_per_tile;
     const uint32_t tile = rp.rank + local_tile * rp.world;
     const uint32_t x = (tile % rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
     const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
-    if (x >= rp.w || y >= rp.h) {
-        if (lane == 0) { dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; }
-        return;
-    }
+    const bool in_image = wave_has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
     uint32_t my_samples = 0;
     f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane */
-    for (uint32_t s0 = 0; s0 < rp.spp; s0 += 64) {
+    for (uint32_t s0 = 0; in_image && s0 < rp.spp; s0 += 64) {
         const uint32_t s = s0 + lane;
         f3 col = mk3(0.f, 0.f, 0.f);
         if (s < rp.spp) {
@@ -92,8 +99,8 @@ __global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* _
         }
     }
     acc = acc / (float)rp.spp; /* image /= nsamples */
-    if (lane == 0) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; }
-    flush_counters(counters, cnt, my_samples);
+    if (wave_has_pixel && lane == 0) { dst[0] = in_image ? acc.x : 0.f; dst[1] = in_image ? acc.y : 0.f; dst[2] = in_image ? acc.z : 0.f; }
+    flush_counters(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
 }
 
 
@@ -458,13 +465,13 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
     void *d_o, *d_d, *d_p, *d_s, *d_c, *d_cnt;
     int rc;
     if ((rc = tmp.get(&d_o, 12 * n)) || (rc = tmp.get(&d_d, 12 * n)) || (rc = tmp.get(&d_p, 4 * n)) || (rc = tmp.get(&d_s, 4 * n)) ||
-        (rc = tmp.get(&d_c, 12 * n)) || (rc = tmp.get(&d_cnt, 32)))
+        (rc = tmp.get(&d_c, 12 * n)) || (rc = tmp.get(&d_cnt, RT_COUNTER_WORDS * 8)))
         return rc;
     HIP_TRY(hipMemcpyAsync(d_o, org, 12 * n, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(d_d, dir, 12 * n, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(d_p, pixel, 4 * n, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(d_s, sample, 4 * n, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, g.stream));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, RT_COUNTER_WORDS * 8, g.stream));
     HIP_TRY(hipEventRecord(g.ev0, g.stream));
     if (r->dev.root_is_leaf)
         hipLaunchKernelGGL(k_trace<false>, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
@@ -474,16 +481,24 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
                            (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
-    uint64_t cnt[4] = {0, 0, 0, 0};
+    std::vector<uint64_t> slots(RT_COUNTER_WORDS);
+    uint64_t cnt[3];
     HIP_TRY(hipMemcpyAsync(rgb, d_c, 12 * n, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 32, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    rt_counters_total(slots.data(), cnt);
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
     }
     return RT_OK;
+}
+
+void rt_counters_total(const uint64_t* h, uint64_t out3[3]) {
+    out3[0] = out3[1] = out3[2] = 0;
+    for (size_t s = 0; s < RT_COUNTER_SLOTS; ++s)
+        for (int k = 0; k < 3; ++k) out3[k] += h[s * RT_COUNTER_STRIDE + k];
 }
 
 size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world) {
@@ -493,7 +508,7 @@ size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_
 }
 
 int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
-                     uint32_t tile_h, uint32_t rank, uint32_t world, float* d_rgb_tiles, uint64_t* d_counters3, void* hip_stream) {
+                     uint32_t tile_h, uint32_t rank, uint32_t world, float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_render: call rt_init first");
     SceneRes* r = find(scene);
     if (!r) return fail(RT_E_HANDLE, "rt_render: unknown scene");
@@ -510,8 +525,8 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     DCamera* d_cam = g.cam_ring + (g.cam_next++ % kCamSlots);
     HIP_TRY(hipMemcpyAsync(d_cam, &dc, sizeof(DCamera), hipMemcpyHostToDevice, st)); /* pageable source: staged before the call returns */
     dim3 grid((unsigned)((waves + 3) / 4));
-    if (r->dev.root_is_leaf) hipLaunchKernelGGL(k_render<false>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters3);
-    else hipLaunchKernelGGL(k_render<true>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters3);
+    if (r->dev.root_is_leaf) hipLaunchKernelGGL(k_render<false>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters);
+    else hipLaunchKernelGGL(k_render<true>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -527,15 +542,17 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
     Scratch tmp;
     void *d_out, *d_cnt;
     int rc;
-    if ((rc = tmp.get(&d_out, bytes)) || (rc = tmp.get(&d_cnt, 32))) return rc;
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, g.stream));
+    if ((rc = tmp.get(&d_out, bytes)) || (rc = tmp.get(&d_cnt, RT_COUNTER_WORDS * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, RT_COUNTER_WORDS * 8, g.stream));
     HIP_TRY(hipEventRecord(g.ev0, g.stream));
     if ((rc = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, rank, world, (float*)d_out, (uint64_t*)d_cnt, g.stream))) return rc;
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
-    uint64_t cnt[4] = {0, 0, 0, 0};
+    std::vector<uint64_t> slots(RT_COUNTER_WORDS);
+    uint64_t cnt[3];
     if (bytes) HIP_TRY(hipMemcpyAsync(rgb_tiles, d_out, bytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 32, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    rt_counters_total(slots.data(), cnt);
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));

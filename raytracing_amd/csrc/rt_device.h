@@ -200,6 +200,44 @@ RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d
     }
     return any;
 }
+/* The same loop for a scene whose root is a leaf (every built-in scene): the leaf list is all
+ * spheres, then all squares, then all meshes -- the order KDTree::buildKDTree collects them in -- so the
+ * three tables are walked directly, and each record is requested one iteration before it is used:
+ * the scalar load then completes behind the arithmetic of the current object instead of stalling
+ * the wave. */
+RT_DEV uint32_t next_index(uint32_t i, uint32_t n) { return i + 1 < n ? i + 1 : i; }
+/* Calls f(record, index) for every record of a table.  Two record buffers alternate: the scalar
+ * load of the next record is issued into the buffer that is not in use, before the arithmetic on
+ * the current one starts, so its latency overlaps that arithmetic.  (With a single buffer the
+ * register allocator reuses the SGPRs and the load can only start once the current record is dead.) */
+template <class Rec, class F>
+RT_DEV void for_each_record(const Rec* tab, uint32_t n, F&& f) {
+    if (!n) return;
+    Rec a = ldc(&tab[0]);
+    for (uint32_t i = 0; i < n; i += 2) {
+        const Rec b = ldc(&tab[next_index(i, n)]);
+        f(a, i);
+        a = ldc(&tab[i + 2 < n ? i + 2 : n - 1]);
+        if (i + 1 < n) f(b, i + 1);
+    }
+}
+RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, HitRec& best) {
+    for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& rec, uint32_t i) {
+        float t;
+        if (sphere_t(rec, o, d, t) && (best.type < 0 || t < best.t)) { best.t = t; best.type = RT_SPHERE; best.obj = (int)i; }
+    });
+    for_each_record(sc.squares, sc.n_squares, [&](const DSquare& rec, uint32_t i) {
+        float t;
+        if (square_t(rec, o, d, t) && (best.type < 0 || t < best.t)) { best.t = t; best.type = RT_SQUARE; best.obj = (int)i; }
+    });
+    for (uint32_t i = 0; i < sc.n_meshes; ++i) {
+        float t, u, v;
+        int tri;
+        if (mesh_closest(sc, ldc(&sc.meshes[i]), o, d, t, tri, u, v) && (best.type < 0 || t < best.t)) {
+            best.t = t; best.type = RT_MESH; best.obj = (int)i; best.tri = tri; best.u = u; best.v = v;
+        }
+    }
+}
 /* shadow query on a leaf: "closest hit exists and its t < dist" == "some object reports t < dist" */
 RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist) {
     for (int r = first; r < first + count; ++r) {
@@ -272,7 +310,7 @@ RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
     if (sc.n_kd == 0) return best;
     if (!KD) { /* the root is a leaf (every built-in scene): only pass / fail of the box matters */
         if (!inside_box(sc.box_lo, sc.box_hi, o) && !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-        leaf_closest(sc, 0, (int)sc.n_refs, o, d, best);
+        root_closest(sc, o, d, best);
     } else {
         if (!box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
         kd_closest(sc, o, d, t_in, t_out, best);
@@ -328,62 +366,59 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
         act[j] = o_inside || box_test(sc.box_lo, sc.box_hi, o, d[j], t_in, t_out);
         occ[j] = false;
     }
-    for (int r = 0; r < (int)sc.n_refs; ++r) {
-        DRef ref = ldc(&sc.refs[r]);
-        if (ref.type == RT_SPHERE) {
-            const DSphere s = ldc(&sc.spheres[ref.object]);
-            f3 oc = o - ld3(s.c);
-            float n = len3(oc);
-            float c = (n * n) - s.r2;
+    /* tables walked directly with one-ahead record fetches, as in root_closest */
+    for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& s, uint32_t) {
+        f3 oc = o - ld3(s.c);
+        float n = len3(oc);
+        float c = (n * n) - s.r2;
 #pragma unroll
-            for (int j = 0; j < RT_SB; ++j) {
-                float a = dot3(d[j], d[j]);
-                float b = dot3(2.f * d[j], oc);
-                float delta = b * b - 4.f * a * c;
-                float t = RT_INF; /* stays +inf (never < dist) when the sphere is missed */
-                if (delta > 0.f) {
-                    float sq = __builtin_sqrtf(delta);
-                    float a2 = 2.f * a;
-                    float t1 = (-b - sq) / a2, t2 = (-b + sq) / a2;
-                    if (t1 > 0.f && t2 > 0.f) t = min_std(t1, t2);
-                    else if (t1 > 0.f) t = t1;
-                    else if (t2 > 0.f) t = t2;
-                } else if (delta == 0.f) {
-                    float t0 = -b / (2.f * a);
-                    if (t0 > 0.f) t = t0;
-                }
-                occ[j] = occ[j] || (t < dist[j]);
+        for (int j = 0; j < RT_SB; ++j) {
+            float a = dot3(d[j], d[j]);
+            float b = dot3(2.f * d[j], oc);
+            float delta = b * b - 4.f * a * c;
+            float t = RT_INF; /* stays +inf (never < dist) when the sphere is missed */
+            if (delta > 0.f) {
+                float sq = __builtin_sqrtf(delta);
+                float a2 = 2.f * a;
+                float t1 = (-b - sq) / a2, t2 = (-b + sq) / a2;
+                if (t1 > 0.f && t2 > 0.f) t = min_std(t1, t2);
+                else if (t1 > 0.f) t = t1;
+                else if (t2 > 0.f) t = t2;
+            } else if (delta == 0.f) {
+                float t0 = -b / (2.f * a);
+                if (t0 > 0.f) t = t0;
             }
-        } else if (ref.type == RT_SQUARE) {
-            const DSquare q = ldc(&sc.squares[ref.object]);
-            f3 v0 = ld3(q.v0), n = ld3(q.n);
-            float num = dot3(v0 - o, n);
-#pragma unroll
-            for (int j = 0; j < RT_SB; ++j) {
-                float tt = num / dot3(d[j], n);
-                if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
-            }
-        } else {
-            const DMesh m = ldc(&sc.meshes[ref.object]);
-            for (uint32_t i = 0; i < m.n_tris; ++i) {
-                const DTri tr = ldc(&sc.tris[m.first_tri + i]);
-                f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
-                f3 sv = o - ld3(tr.v0);
-                f3 qv = cross3(sv, e1);
-                float e2q = dot3(e2, qv);
-#pragma unroll
-                for (int j = 0; j < RT_SB; ++j) {
-                    f3 h = cross3(d[j], e2);
-                    float a = dot3(e1, h);
-                    float f = 1.0f / a;
-                    float u = f * dot3(sv, h);
-                    float v = f * dot3(d[j], qv);
-                    float t = f * e2q;
-                    bool ok = !(__builtin_fabsf(a) < 1e-6f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && t > 1e-6f && t < dist[j];
-                    occ[j] = occ[j] || ok;
-                }
-            }
+            occ[j] = occ[j] || (t < dist[j]);
         }
+    });
+    for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t) {
+        f3 v0 = ld3(q.v0), n = ld3(q.n);
+        float num = dot3(v0 - o, n);
+#pragma unroll
+        for (int j = 0; j < RT_SB; ++j) {
+            float tt = num / dot3(d[j], n);
+            if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
+        }
+    });
+    for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
+        const DMesh m = ldc(&sc.meshes[mi]);
+        for_each_record(sc.tris + m.first_tri, m.n_tris, [&](const DTri& tr, uint32_t) {
+            f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+            f3 sv = o - ld3(tr.v0);
+            f3 qv = cross3(sv, e1);
+            float e2q = dot3(e2, qv);
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j) {
+                f3 h = cross3(d[j], e2);
+                float a = dot3(e1, h);
+                float f = 1.0f / a;
+                float u = f * dot3(sv, h);
+                float v = f * dot3(d[j], qv);
+                float t = f * e2q;
+                bool ok = !(__builtin_fabsf(a) < 1e-6f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && t > 1e-6f && t < dist[j];
+                occ[j] = occ[j] || ok;
+            }
+        });
     }
 #pragma unroll
     for (int j = 0; j < RT_SB; ++j) occ[j] = occ[j] && act[j];
@@ -452,10 +487,19 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         Ld[j] = norm3(L[j]); /* Ray() normalises L again */
                         dist[j] = len3(SP);
                     }
+#if defined(RT_ABLATE) && (RT_ABLATE & 1)
+                    for (int j = 0; j < RT_SB; ++j) { occ[j] = false; asm volatile("" ::"v"(Ld[j].x), "v"(dist[j])); }
+                    cnt.rays += RT_SB;
+#else
                     shadow_batch(sc, so, so_inside, Ld, dist, occ, cnt);
+#endif
 #pragma unroll
                     for (int j = 0; j < RT_SB; ++j)
+#if defined(RT_ABLATE) && (RT_ABLATE & 2)
+                        if (!occ[j]) { sum.x += L[j].x; asm volatile("" ::"v"(L[j].y), "v"(L[j].z)); }
+#else
                         if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
+#endif
                 }
             } else
                 for (int i = 0; i < 16; ++i) {
