@@ -922,7 +922,7 @@ void orc_scene_kdtree(orc_scene* h, int32_t* nodes, uint32_t* n_nodes, int32_t* 
         if (nodes) {
             int32_t* o = nodes + 8 * i;
             o[0] = k.leaf; o[1] = k.axis; std::memcpy(&o[2], &k.cut, 4);
-            o[3] = k.left; o[4] = k.right; o[5] = (int32_t)nr; o[6] = (int32_t)k.refs.size(); o[7] = k.depth;
+            o[3] = k.left; o[4] = k.right; o[5] = k.leaf ? (int32_t)nr : 0; o[6] = (int32_t)k.refs.size(); o[7] = k.depth;
         }
         for (const Ref& r : k.refs) {
             if (refs) { refs[2 * nr] = r.type; refs[2 * nr + 1] = r.object; }

@@ -178,3 +178,53 @@ def test_scene3_matches_reference_render_statistically(golden_dir):
     assert abs(q.mean() - gold.mean()) < 2e-3
     assert psnr(q, gold) > 30.0
     g.close()
+
+
+# ---- scenes with more than 30 objects: the object kd-tree has internal nodes, KDTree::intersectNode's
+# near / far rules (and its misses) must be reproduced exactly --------------------------------------------
+from tests import scenegen  # noqa: E402
+
+
+@pytest.fixture(scope="module", params=[(40, 24, 3, False), (70, 0, 5, True), (10, 60, 9, False)])
+def kd_pair(request):
+    ns, nq, seed, point = request.param
+    d, keep = scenegen.random_objects(orc, ns, nq, seed, point_light=point)
+    o = orc.Scene.from_desc(d, keep)
+    g = api.DeviceScene(o.desc, keep=o)
+    yield o, g
+    g.close()
+
+
+def test_kd_internal_nodes_tree_and_hits(kd_pair):
+    o, g = kd_pair
+    on, orf, ob = o.kdtree()
+    gn, grf, gb = g.kdtree()
+    assert (on[:, 0] == 0).sum() >= 1, "scene must produce internal kd nodes"
+    assert np.array_equal(on, gn) and np.array_equal(orf, grf) and np.array_equal(_bits(ob), _bits(gb))
+    org, d = rayset.mixed(orc, n_each=6000)
+    a, b = o.intersect(org, d), g.intersect(org, d)
+    assert a["hit"].sum() > 1000
+    assert_hits_equal(a, b, "kd scene")
+
+
+def test_kd_internal_nodes_trace(kd_pair):
+    o, g = kd_pair
+    w, h, spp = 48, 48, 2
+    rng = np.random.default_rng(31)
+    ys, xs = np.mgrid[0:h, 0:w]
+    pix = np.repeat((xs + ys * w).ravel().astype(np.uint32), spp)
+    smp = np.tile(np.arange(spp, dtype=np.uint32), w * h)
+    u = ((np.repeat(xs.ravel(), spp) + rng.random(pix.size)) / w).astype(np.float32)
+    v = ((np.repeat(ys.ravel(), spp) + rng.random(pix.size)) / h).astype(np.float32)
+    org, d = orc.generate_rays(orc.camera_default(w, h), u, v)
+    oc, ost = o.trace(org, d, pix, smp, seed=2, k0=2)
+    gc, gst = g.trace(org, d, pix, smp, seed=2, k0=2)
+    assert (ost.rays, ost.samples, ost.nodes) == (gst.rays, gst.samples, gst.nodes)
+    both = np.isfinite(oc) & np.isfinite(gc)
+    assert (np.isfinite(oc) == np.isfinite(gc)).all()
+    assert np.abs(oc[both] - gc[both]).max() <= 5e-6  # generic shininess goes through pow(): a few ulp more than the x^16 path
+    img_o, so = o.render(orc.camera_default(40, 30), 40, 30, 2, orc.RT_RNG_COUNTER, seed=4, threads=4)
+    img_g, sg = g.render(orc.camera_default(40, 30), 40, 30, 2, seed=4, tile_w=8, tile_h=8)
+    assert so.rays == sg.rays
+    ok = np.isfinite(img_o) & np.isfinite(img_g)
+    assert np.abs(img_o[ok] - img_g[ok]).max() <= 5e-6
