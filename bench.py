@@ -64,7 +64,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from raytracing_amd import api, host
+    from raytracing_amd import api, host, parallel_render
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,40 +78,31 @@ def main():
     api.init(local_rank)
 
     w, h, spp, tw, th = args.width, args.height, args.spp, args.tile, args.tile
-    scene = host.HostScene.builtin(2).upload()          # Cornell box, product host code
+    scene = host.HostScene.builtin(2).upload()          # Cornell box, built by the product's host code
     cam = host.camera_default(w, h)
-    per_rank = api.tiles_per_rank(w, h, tw, th, 0, world)  # rank 0 holds the most tiles
-    tile_floats = tw * th * 3
-    mine = torch.zeros(per_rank * tile_floats, dtype=torch.float32, device=dev)
-    gathered = [torch.empty_like(mine) for _ in range(world)] if (rank == 0 and world > 1) else None
-    counters = torch.zeros(api.COUNTER_SLOTS, api.COUNTER_STRIDE, dtype=torch.int64, device=dev)
-    image = torch.zeros(h * w * 3, dtype=torch.float32, device=dev) if rank == 0 else None
-
-    # scatter map tile-major -> row-major for rank 0 (built once, lives in HBM)
-    perm = None
-    if rank == 0:
-        tx = (w + tw - 1) // tw
-        ys, xs = np.mgrid[0:h, 0:w]
-        t = (ys // th) * tx + (xs // tw)
-        src = ((t % world) * per_rank + t // world) * (tw * th) + (ys % th) * tw + (xs % tw)
-        perm = torch.from_numpy(src.ravel().astype(np.int64)).to(dev)
-
+    counters = parallel_render.new_counters(dev)
+    renderer = parallel_render.ShardedRenderer(
+        w, h, tw, th, dev, parallel_render.device_render_fn(scene, cam, w, h, spp, args.seed, tw, th, counters))
     stream = torch.cuda.current_stream(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    image = None
 
     def step(i=None):
+        nonlocal image
+        image = renderer.step()
+
+    # kernel-only timing: HIP events on the launch stream around the render call of each timed step
+    inner = renderer.render_tiles_fn
+    tick = {"i": None}
+
+    def timed_render(out, r, wd):
+        i = tick["i"]
         if i is not None:
             ev[i][0].record(stream)
-        scene.render_device(cam, w, h, spp, args.seed, tw, th, rank, world, mine.data_ptr(), counters.data_ptr(),
-                            stream.cuda_stream)
+        inner(out, r, wd)
         if i is not None:
             ev[i][1].record(stream)
-        if world > 1:
-            dist.gather(mine, gathered, dst=0)
-            if rank == 0:
-                torch.index_select(torch.cat(gathered).view(-1, 3), 0, perm, out=image.view(-1, 3))
-        else:
-            torch.index_select(mine.view(-1, 3), 0, perm, out=image.view(-1, 3))
+    renderer.render_tiles_fn = timed_render
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -126,6 +117,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        tick["i"] = i
         step(i)
     fence()
     dt = time.perf_counter() - t0
@@ -143,7 +135,7 @@ def main():
         rays_total, samples_total, dt_max, kernel_ms_max = stats[0].item(), stats[1].item(), dt, kernel_ms
 
     if rank == 0:
-        img = image.view(h, w, 3)
+        img = image
         assert torch.isfinite(img).all() and float(img.mean()) > 0.01, "render produced an empty / non-finite image"
         cpu_rec, flop_per_ray = None, args.flop_per_ray
         if world == 1 and args.cpu_spp > 0:
