@@ -60,7 +60,7 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     }
 }
 
-template <bool KD>
+template <int M>
 __global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63;
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* _
     const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
     const bool in_image = wave_has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
+    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
     uint32_t my_samples = 0;
     f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane */
     for (uint32_t s0 = 0; in_image && s0 < rp.spp; s0 += 64) {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* _
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
             primary_ray(cam, u, v, &o, &d);
-            col = trace_path<KD>(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
+            col = trace_path<M>(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
             ++my_samples;
         }
         /* image[x + y*w] += color, one sample after the other */
@@ -119,16 +120,17 @@ RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u,
     return r;
 }
 
-template <bool KD>
+template <int M>
 __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir,
                                                    size_t n, rt_hit* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
-    HitRec rec = closest_rec<KD>(sc, o, d, cnt);
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
+    HitRec rec = closest_rec<M>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
-    int tri = (h.hit && h.type == RT_MESH) ? (int)(h.tri - (int)ldc(&sc.meshes[h.obj].first_tri)) : -1;
+    int tri = (h.hit && h.type == RT_MESH) ? (int)ldc(&sc.tri_orig[h.tri]) : -1;
     out[i] = pack_hit(h, h.type, h.obj, tri, rec.u, rec.v);
 }
 
@@ -138,23 +140,25 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     if (i >= n) return;
     f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
     HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
+    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     const DMesh m = ldc(&sc.meshes[mesh]);
-    if (mesh_closest(sc, m, o, d, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
+    if (mesh_closest<RT_M_BVH>(sc, m, o, d, s_stack + threadIdx.x, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
     FullHit h = finish_hit(sc, rec, o, d);
-    out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)(h.tri - (int)m.first_tri) : -1, rec.u, rec.v);
+    out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)ldc(&sc.tri_orig[h.tri]) : -1, rec.u, rec.v);
 }
 
-template <bool KD>
+template <int M>
 __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
                                                const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
+    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
     uint32_t smp = 0;
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
         Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
-        f3 c = trace_path<KD>(sc, o, d, rng, cnt);
+        f3 c = trace_path<M>(sc, o, d, rng, cnt);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
         smp = 1;
     }
@@ -177,9 +181,21 @@ __global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __re
 
 namespace {
 
+/* launches kernel<mode>: mode = RT_M_KD | RT_M_BVH bits of the scene */
+#define RT_DISPATCH(mode, kernel, grid, stream, ...)                                                   \
+    do {                                                                                               \
+        switch (mode) {                                                                                \
+            case 0: hipLaunchKernelGGL(kernel<0>, grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+            case 1: hipLaunchKernelGGL(kernel<1>, grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+            case 2: hipLaunchKernelGGL(kernel<2>, grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+            default: hipLaunchKernelGGL(kernel<3>, grid, dim3(256), 0, stream, __VA_ARGS__); break;     \
+        }                                                                                              \
+    } while (0)
+
 struct SceneRes {
     rtb::Built host;
     DeviceScene dev{};
+    int mode = 0;
     std::vector<void*> allocs;
 };
 
@@ -323,6 +339,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
     int rc;
     if ((rc = upload(r, r->host.spheres, &d.spheres)) || (rc = upload(r, r->host.squares, &d.squares)) ||
         (rc = upload(r, r->host.meshes, &d.meshes)) || (rc = upload(r, r->host.tris, &d.tris)) ||
+        (rc = upload(r, r->host.tri_orig, &d.tri_orig)) || (rc = upload(r, r->host.bvh, &d.bvh)) ||
         (rc = upload(r, r->host.normals, &d.normals)) || (rc = upload(r, r->host.materials, &d.materials)) ||
         (rc = upload(r, r->host.lights, &d.lights)) || (rc = upload(r, r->host.kd, &d.kd)) ||
         (rc = upload(r, r->host.refs, &d.refs))) {
@@ -335,6 +352,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
     for (int a = 0; a < 3; ++a) { d.box_lo[a] = r->host.box_lo[a]; d.box_hi[a] = r->host.box_hi[a]; }
     d.kd_epsilon = r->host.kd_epsilon;
     d.root_is_leaf = (!r->host.kd.empty() && r->host.kd[0].leaf) ? 1 : 0;
+    r->mode = (d.root_is_leaf ? 0 : RT_M_KD) | (r->host.bvh.empty() ? 0 : RT_M_BVH);
     rt_scene_t h = g.next_handle++;
     g.scenes[h] = r;
     *out = h;
@@ -383,8 +401,7 @@ int rt_intersect_device(rt_scene_t scene, const float* d_org, const float* d_dir
     if (!d_org || !d_dir || !d_out) return fail(RT_E_INVALID, "rt_intersect: null buffer");
     if (n > 0x7fffffffull * 256) return fail(RT_E_LIMIT, "rt_intersect: too many rays for one launch");
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
-    if (r->dev.root_is_leaf) hipLaunchKernelGGL(k_intersect<false>, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
-    else hipLaunchKernelGGL(k_intersect<true>, dim3(blocks_for(n)), dim3(256), 0, st, r->dev, d_org, d_dir, n, d_out);
+    RT_DISPATCH(r->mode, k_intersect, dim3(blocks_for(n)), st, r->dev, d_org, d_dir, n, d_out);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -473,12 +490,8 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
     HIP_TRY(hipMemcpyAsync(d_s, sample, 4 * n, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, RT_COUNTER_WORDS * 8, g.stream));
     HIP_TRY(hipEventRecord(g.ev0, g.stream));
-    if (r->dev.root_is_leaf)
-        hipLaunchKernelGGL(k_trace<false>, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
-                           (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
-    else
-        hipLaunchKernelGGL(k_trace<true>, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, (const float*)d_o, (const float*)d_d, n,
-                           (const uint32_t*)d_p, (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
+    RT_DISPATCH(r->mode, k_trace, dim3(blocks_for(n)), g.stream, r->dev, (const float*)d_o, (const float*)d_d, n, (const uint32_t*)d_p,
+                (const uint32_t*)d_s, seed, k0, (float*)d_c, (uint64_t*)d_cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
     std::vector<uint64_t> slots(RT_COUNTER_WORDS);
@@ -525,8 +538,7 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     DCamera* d_cam = g.cam_ring + (g.cam_next++ % kCamSlots);
     HIP_TRY(hipMemcpyAsync(d_cam, &dc, sizeof(DCamera), hipMemcpyHostToDevice, st)); /* pageable source: staged before the call returns */
     dim3 grid((unsigned)((waves + 3) / 4));
-    if (r->dev.root_is_leaf) hipLaunchKernelGGL(k_render<false>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters);
-    else hipLaunchKernelGGL(k_render<true>, grid, dim3(256), 0, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters);
+    RT_DISPATCH(r->mode, k_render, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

@@ -119,6 +119,124 @@ void edge_interval(float len, float& lo, float& hi) {
     hi = std::isnan(b) ? std::numeric_limits<float>::infinity() : b;
 }
 
+
+/* ---- triangle BVH (per mesh) ---------------------------------------------------------------
+ * Binned surface-area-heuristic build over the scaled triangles the device tests (v0, v0+e1, v0+e2).
+ * Leaves hold at most 4 triangles; if the SAH recursion gets deeper than kBvhMaxDepth it switches
+ * to median splits, which bounds the depth (and the device's traversal stack).  Leaf triangles are
+ * written back in leaf order, with their original indices kept in tri_orig. */
+struct BBox {
+    float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const BBox& b) { grow(b.lo); grow(b.hi); }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0 || dy < 0 || dz < 0) ? 0.f : 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+struct TriInfo { BBox box; float c[3]; uint32_t id; };
+
+struct BvhBuilder {
+    std::vector<TriInfo>& prims;
+    std::vector<DBvhNode>& nodes;
+    std::vector<uint32_t> order; /* triangle ids in leaf order */
+    float pad;
+    BvhBuilder(std::vector<TriInfo>& p, std::vector<DBvhNode>& n, float pad_) : prims(p), nodes(n), pad(pad_) {}
+
+    struct Child { bool leaf; int32_t index; int32_t count; BBox box; };
+
+    Child build(uint32_t first, uint32_t count, int depth) {
+        BBox box, cbox;
+        for (uint32_t i = first; i < first + count; ++i) { box.grow(prims[i].box); cbox.grow(prims[i].c); }
+        if (count <= 4) return make_leaf(first, count, box);
+        int axis = 0;
+        float ext[3] = {cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        uint32_t mid = first + count / 2;
+        bool split_ok = false;
+        if (depth < kBvhMaxDepth - 24 && ext[axis] > 0.f) { /* binned SAH */
+            const int B = 16;
+            BBox bb[B]; uint32_t bn[B] = {0};
+            float k = B * (1.f - 1e-6f) / ext[axis];
+            auto bin_of = [&](const TriInfo& t) { int b = (int)((t.c[axis] - cbox.lo[axis]) * k); return b < 0 ? 0 : (b >= B ? B - 1 : b); };
+            for (uint32_t i = first; i < first + count; ++i) { int b = bin_of(prims[i]); bb[b].grow(prims[i].box); ++bn[b]; }
+            float right_area[B]; BBox acc; uint32_t nacc = 0;
+            for (int b = B - 1; b > 0; --b) { acc.grow(bb[b]); right_area[b] = acc.area(); }
+            BBox left; float best = kInf; int best_b = -1; uint32_t nl = 0;
+            for (int b = 0; b < B - 1; ++b) {
+                left.grow(bb[b]); nl += bn[b];
+                uint32_t nr = count - nl;
+                if (nl == 0 || nr == 0) continue;
+                float cost = left.area() * nl + right_area[b + 1] * nr;
+                if (cost < best) { best = cost; best_b = b; }
+            }
+            (void)nacc;
+            if (best_b >= 0) {
+                auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const TriInfo& t) { return bin_of(t) <= best_b; });
+                mid = (uint32_t)(it - prims.begin());
+                split_ok = mid > first && mid < first + count;
+            }
+        }
+        if (!split_ok) { /* median split along the widest centroid axis: halves the range */
+            mid = first + count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                             [&](const TriInfo& a, const TriInfo& b) { return a.c[axis] < b.c[axis]; });
+        }
+        int32_t id = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Child l = build(first, mid - first, depth + 1);
+        Child r = build(mid, first + count - mid, depth + 1);
+        DBvhNode& n = nodes[id];
+        store(n.lo0, n.hi0, n.c0, n.n0, l);
+        store(n.lo1, n.hi1, n.c1, n.n1, r);
+        return Child{false, id, 0, box};
+    }
+    Child make_leaf(uint32_t first, uint32_t count, const BBox& box) {
+        int32_t start = (int32_t)order.size();
+        for (uint32_t i = first; i < first + count; ++i) order.push_back(prims[i].id);
+        return Child{true, start, (int32_t)count, box};
+    }
+    void store(float* lo, float* hi, int32_t& c, int32_t& n, const Child& ch) {
+        for (int a = 0; a < 3; ++a) { lo[a] = ch.box.lo[a] - pad; hi[a] = ch.box.hi[a] + pad; }
+        c = ch.index; n = ch.leaf ? ch.count : 0;
+    }
+};
+
+/* Builds the BVH of the triangles [first, first+count) of out.tris, reorders them into leaf order
+ * and returns the root node index (a mesh with one leaf still gets a root node). */
+int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count) {
+    std::vector<TriInfo> prims(count);
+    BBox all;
+    for (uint32_t i = 0; i < count; ++i) {
+        const DTri& t = out.tris[first + i];
+        float v1[3], v2[3];
+        for (int a = 0; a < 3; ++a) { v1[a] = t.v0[a] + t.e1[a]; v2[a] = t.v0[a] + t.e2[a]; }
+        TriInfo& p = prims[i];
+        p.box.grow(t.v0); p.box.grow(v1); p.box.grow(v2);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        p.id = i;
+        all.grow(p.box);
+    }
+    float diag = std::sqrt((all.hi[0] - all.lo[0]) * (all.hi[0] - all.lo[0]) + (all.hi[1] - all.lo[1]) * (all.hi[1] - all.lo[1]) +
+                           (all.hi[2] - all.lo[2]) * (all.hi[2] - all.lo[2]));
+    float pad = 1e-4f * diag + 1e-6f; /* covers the rounding of the float ray / triangle test near box faces */
+    int32_t root = (int32_t)out.bvh.size();
+    BvhBuilder b(prims, out.bvh, pad);
+    BvhBuilder::Child top = b.build(0, count, 0);
+    if (top.leaf) return -1; /* cannot happen for count > 4; the caller then keeps the brute-force loop */
+    /* leaf indices are relative to this mesh: make them global, and permute the triangles */
+    std::vector<DTri> sorted(count);
+    for (uint32_t i = 0; i < count; ++i) { sorted[i] = out.tris[first + b.order[i]]; out.tri_orig[first + i] = b.order[i]; }
+    std::copy(sorted.begin(), sorted.end(), out.tris.begin() + first);
+    for (size_t k = (size_t)root; k < out.bvh.size(); ++k) {
+        DBvhNode& n = out.bvh[k];
+        if (n.n0 > 0) n.c0 += (int32_t)first;
+        if (n.n1 > 0) n.c1 += (int32_t)first;
+    }
+    return root;
+}
+
 }  // namespace
 
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
@@ -178,7 +296,9 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
             st(tr.v0, v0); st(tr.e1, v1 - v0); st(tr.e2, v2 - v0);
             tr.i0 = m.first_vertex + idx[0]; tr.i1 = m.first_vertex + idx[1]; tr.i2 = m.first_vertex + idx[2];
             out.tris.push_back(tr);
+            out.tri_orig.push_back(t);
         }
+        if (m.n_triangles > kBvhMinTris) o.bvh_root = build_mesh_bvh(out, o.first_tri, o.n_tris);
         out.meshes.push_back(o);
     }
     out.normals.assign(d.normals, d.normals + 3 * (size_t)d.n_vertices);

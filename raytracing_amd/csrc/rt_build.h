@@ -15,6 +15,8 @@ struct Built {
     std::vector<DSquare> squares;
     std::vector<DMesh> meshes;
     std::vector<DTri> tris;
+    std::vector<uint32_t> tri_orig;
+    std::vector<DBvhNode> bvh;
     std::vector<float> normals;
     std::vector<DMaterial> materials;
     std::vector<DLight> lights;
@@ -24,6 +26,9 @@ struct Built {
     float kd_epsilon = 0.01f;
 };
 
+/* meshes with more than kBvhMinTris triangles get a BVH; smaller ones keep the reference's loop */
+const uint32_t kBvhMinTris = 64;
+const int kBvhMaxDepth = 60;
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err);
 bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err);
 

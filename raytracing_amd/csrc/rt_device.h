@@ -57,8 +57,16 @@ RT_DEV T ldc(const T* p) {
     return u.v;
 }
 
-/* per-lane work counters; summed over the wave and added to global memory once per wave */
-struct Cnt { uint32_t rays, nodes; };
+/* per-lane context: work counters (summed per workgroup at the end) and the base of this lane's
+ * slice of the LDS traversal stack (element i lives at stack[i * RT_STACK_STRIDE]) */
+struct Cnt { uint32_t rays, nodes; uint32_t* stack; };
+/* kernel variants: bit 0 = the object kd-tree has internal nodes, bit 1 = some mesh has a triangle BVH.
+ * Code a scene cannot reach is compiled out of its variant, which keeps the common variant's registers low. */
+#define RT_M_KD 1
+#define RT_M_BVH 2
+#define RT_STACK_LDS 16      /* entries per lane kept in LDS */
+#define RT_STACK_SPILL 48    /* deeper entries go to a per-lane private array */
+#define RT_STACK_STRIDE 256  /* workgroup size: lane-interleaved, conflict-free LDS layout */
 
 /* closest hit so far: enough to rebuild position and normal of the winner afterwards */
 struct HitRec {
@@ -162,8 +170,90 @@ RT_DEV bool tri_t(const DTri& tr, f3 o, f3 d, float& t, float& u, float& v) {
     return true;
 }
 
+/* ---- per-mesh triangle BVH traversal -------------------------------------------------------
+ * Replaces the brute-force loop of Mesh::intersect (R/src/Mesh.h:225-277) for large meshes without
+ * changing its answer: every triangle test is the reference's arithmetic (tri_t), the winner is
+ * the smallest t and, on equal t, the smallest original index -- what the loop's strict `<` keeps.
+ * The boxes only decide which triangles get tested; they are padded on the host and a subtree is
+ * skipped only when its box is missed or starts beyond the best t so far.
+ * while-while form: descend through inner nodes until a leaf entry is reached, then test the
+ * leaf's triangles; one 64-byte node holds both child boxes.  The stack keeps its first
+ * RT_STACK_LDS entries in LDS (lane-interleaved) and spills deeper ones to private memory.
+ * Stack entries: >= 0 inner node index; < 0 leaf, ~entry = first_triangle * 8 + count (count <= 4). */
+RT_DEV bool slab(const float lo[3], const float hi[3], f3 o, f3 id, float limit, float& tn) {
+    float x1 = (lo[0] - o.x) * id.x, x2 = (hi[0] - o.x) * id.x;
+    float y1 = (lo[1] - o.y) * id.y, y2 = (hi[1] - o.y) * id.y;
+    float z1 = (lo[2] - o.z) * id.z, z2 = (hi[2] - o.z) * id.z;
+    /* fminf / fmaxf drop a NaN operand (0 * inf when the ray runs inside a face plane): that axis
+     * then does not constrain the interval, which is the conservative reading */
+    tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.f));
+    float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), limit));
+    return tn <= tf;
+}
+template <bool ANY>
+RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, uint32_t* stack, float& best_t, int& best_tri,
+                         float& best_u, float& best_v) {
+    const f3 id = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t spill[RT_STACK_SPILL];
+    int sp = 0;
+    bool found = false;
+    best_t = ANY ? dist : 3.402823466e+38f; /* FLT_MAX, the reference's initial closest t */
+    uint32_t best_orig = 0xffffffffu;
+    int cur = m.bvh_root;
+    auto push = [&](int e) {
+        if (sp < RT_STACK_LDS) stack[sp * RT_STACK_STRIDE] = (uint32_t)e;
+        else if (sp < RT_STACK_LDS + RT_STACK_SPILL) spill[sp - RT_STACK_LDS] = (uint32_t)e;
+        ++sp; /* the host bounds the tree depth, so the stack cannot overflow */
+    };
+    auto pop = [&]() -> int {
+        --sp;
+        return (int)(sp < RT_STACK_LDS ? stack[sp * RT_STACK_STRIDE] : spill[sp - RT_STACK_LDS]);
+    };
+    for (;;) {
+        bool done = false;
+        while (cur >= 0) { /* inner nodes */
+            const DBvhNode n = ldc(&sc.bvh[cur]);
+            float t0, t1;
+            bool h0 = slab(n.lo0, n.hi0, o, id, best_t, t0) && !(n.n0 == 0 && n.c0 < 0);
+            bool h1 = slab(n.lo1, n.hi1, o, id, best_t, t1) && !(n.n1 == 0 && n.c1 < 0);
+            int e0 = n.n0 > 0 ? ~(n.c0 * 8 + n.n0) : n.c0;
+            int e1 = n.n1 > 0 ? ~(n.c1 * 8 + n.n1) : n.c1;
+            if (h0 && h1) {
+                bool first0 = t0 <= t1;
+                push(first0 ? e1 : e0);
+                cur = first0 ? e0 : e1;
+            } else if (h0) cur = e0;
+            else if (h1) cur = e1;
+            else if (sp > 0) cur = pop();
+            else { done = true; break; }
+        }
+        if (done) break;
+        { /* leaf */
+            int code = ~cur;
+            int first = code >> 3, count = code & 7;
+            for (int k = 0; k < count; ++k) {
+                float t, u, v;
+                if (tri_t(ldc(&sc.tris[first + k]), o, d, t, u, v) && t > 1e-6f) {
+                    if (ANY) { if (t < dist) return true; }
+                    else {
+                        uint32_t orig = ldc(&sc.tri_orig[first + k]);
+                        if (t < best_t || (t == best_t && orig < best_orig)) {
+                            best_t = t; best_tri = first + k; best_u = u; best_v = v; best_orig = orig; found = true;
+                        }
+                    }
+                }
+            }
+            if (sp > 0) cur = pop();
+            else break;
+        }
+    }
+    return found;
+}
+
 /* ---- Mesh::intersect closest loop, R/src/Mesh.h:225-277 (brute force over the slice) ----- */
-RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float& best_t, int& best_tri, float& best_u, float& best_v) {
+template <int M>
+RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, uint32_t* stack, float& best_t, int& best_tri, float& best_u, float& best_v) {
+    if ((M & RT_M_BVH) && m.bvh_root >= 0) return bvh_traverse<false>(sc, m, o, d, 0.f, stack, best_t, best_tri, best_u, best_v);
     bool found = false;
     best_t = 3.402823466e+38f; /* FLT_MAX */
     for (uint32_t i = 0; i < m.n_tris; ++i) {
@@ -174,7 +264,13 @@ RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
     }
     return found;
 }
-RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist) {
+template <int M>
+RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, uint32_t* stack) {
+    if ((M & RT_M_BVH) && m.bvh_root >= 0) {
+        float t, u, v;
+        int tri;
+        return bvh_traverse<true>(sc, m, o, d, dist, stack, t, tri, u, v);
+    }
     for (uint32_t i = 0; i < m.n_tris; ++i) {
         float t, u, v;
         if (tri_t(ldc(&sc.tris[m.first_tri + i]), o, d, t, u, v) && t > 1e-6f && t < dist) return true;
@@ -183,7 +279,8 @@ RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
 }
 
 /* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------ */
-RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, HitRec& best) {
+template <int M>
+RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, uint32_t* stack, HitRec& best) {
     bool any = false;
     for (int r = first; r < first + count; ++r) {
         DRef ref = ldc(&sc.refs[r]);
@@ -192,7 +289,7 @@ RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d
         bool ok;
         if (ref.type == RT_SPHERE) ok = sphere_t(ldc(&sc.spheres[ref.object]), o, d, t);
         else if (ref.type == RT_SQUARE) ok = square_t(ldc(&sc.squares[ref.object]), o, d, t);
-        else ok = mesh_closest(sc, ldc(&sc.meshes[ref.object]), o, d, t, tri, u, v);
+        else ok = mesh_closest<M>(sc, ldc(&sc.meshes[ref.object]), o, d, stack, t, tri, u, v);
         if (ok) {
             any = true;
             if (best.type < 0 || t < best.t) { best.t = t; best.type = ref.type; best.obj = ref.object; best.tri = tri; best.u = u; best.v = v; }
@@ -221,7 +318,8 @@ RT_DEV void for_each_record(const Rec* tab, uint32_t n, F&& f) {
         if (i + 1 < n) f(b, i + 1);
     }
 }
-RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, HitRec& best) {
+template <int M>
+RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, uint32_t* stack, HitRec& best) {
     for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& rec, uint32_t i) {
         float t;
         if (sphere_t(rec, o, d, t) && (best.type < 0 || t < best.t)) { best.t = t; best.type = RT_SPHERE; best.obj = (int)i; }
@@ -233,19 +331,20 @@ RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, HitRec& best) {
     for (uint32_t i = 0; i < sc.n_meshes; ++i) {
         float t, u, v;
         int tri;
-        if (mesh_closest(sc, ldc(&sc.meshes[i]), o, d, t, tri, u, v) && (best.type < 0 || t < best.t)) {
+        if (mesh_closest<M>(sc, ldc(&sc.meshes[i]), o, d, stack, t, tri, u, v) && (best.type < 0 || t < best.t)) {
             best.t = t; best.type = RT_MESH; best.obj = (int)i; best.tri = tri; best.u = u; best.v = v;
         }
     }
 }
 /* shadow query on a leaf: "closest hit exists and its t < dist" == "some object reports t < dist" */
-RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist) {
+template <int M>
+RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist, uint32_t* stack) {
     for (int r = first; r < first + count; ++r) {
         DRef ref = ldc(&sc.refs[r]);
         float t;
         if (ref.type == RT_SPHERE) { if (sphere_t(ldc(&sc.spheres[ref.object]), o, d, t) && t < dist) return true; }
         else if (ref.type == RT_SQUARE) { if (square_t(ldc(&sc.squares[ref.object]), o, d, t) && t < dist) return true; }
-        else { if (mesh_any(sc, ldc(&sc.meshes[ref.object]), o, d, dist)) return true; }
+        else { if (mesh_any<M>(sc, ldc(&sc.meshes[ref.object]), o, d, dist, stack)) return true; }
     }
     return false;
 }
@@ -255,7 +354,8 @@ RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, fl
  * boolean each call returns (something in that subtree was hit) is kept, because the reference
  * uses it to decide whether the far child is visited. */
 #define RT_KD_MAX_DEPTH 16
-RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_out, HitRec& best) {
+template <int M>
+RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_out, uint32_t* stack, HitRec& best) {
     /* frame = far child id * 4 + state, plane distance, exit distance of the level.
      * state 0: near subtree running; 1 / 2: far subtree running after near returned false / true */
     int f_node[RT_KD_MAX_DEPTH];
@@ -265,7 +365,7 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
     for (;;) {
         for (;;) { /* descend until a leaf */
             DKdNode nd = ldc(&sc.kd[node]);
-            if (nd.leaf) { ret = leaf_closest(sc, nd.first_ref, nd.n_refs, o, d, best); break; }
+            if (nd.leaf) { ret = leaf_closest<M>(sc, nd.first_ref, nd.n_refs, o, d, stack, best); break; }
             float da = comp(d, nd.axis), oa = comp(o, nd.axis);
             float t_split = (__builtin_fabsf(da) < sc.kd_epsilon) ? RT_INF : (nd.cut - oa) / da;
             int near_id = (da >= 0.f) ? nd.left : nd.right;
@@ -301,19 +401,19 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
 }
 
 /* ---- Scene::computeIntersection, R/src/Scene.h:169-205 via KDTree::intersect :679-687 ----- */
-template <bool KD>
+template <int M>
 RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
     ++cnt.rays;
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     float t_in, t_out;
     if (sc.n_kd == 0) return best;
-    if (!KD) { /* the root is a leaf (every built-in scene): only pass / fail of the box matters */
+    if (!(M & RT_M_KD)) { /* the root is a leaf (every built-in scene): only pass / fail of the box matters */
         if (!inside_box(sc.box_lo, sc.box_hi, o) && !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-        root_closest(sc, o, d, best);
+        root_closest<M>(sc, o, d, cnt.stack, best);
     } else {
         if (!box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-        kd_closest(sc, o, d, t_in, t_out, best);
+        kd_closest<M>(sc, o, d, t_in, t_out, cnt.stack, best);
     }
     return best;
 }
@@ -336,15 +436,15 @@ RT_DEV FullHit finish_hit(const DeviceScene& sc, const HitRec& r, f3 o, f3 d) {
 }
 
 /* shadow test of Scene::phong, R/src/Scene.h:379-384: closest hit exists and t < dist */
-template <bool KD>
+template <int M>
 RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
     ++cnt.rays;
     float t_in, t_out;
     if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return false;
-    if (!KD) return leaf_any(sc, 0, (int)sc.n_refs, o, d, dist);
+    if (!(M & RT_M_KD)) return leaf_any<M>(sc, 0, (int)sc.n_refs, o, d, dist, cnt.stack);
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
-    return kd_closest(sc, o, d, t_in, t_out, best) && best.type >= 0 && best.t < dist;
+    return kd_closest<M>(sc, o, d, t_in, t_out, cnt.stack, best) && best.type >= 0 && best.t < dist;
 }
 
 /* Shadow queries of one shaded point, RT_SB at a time (root-leaf scenes).  All rays of a batch leave the
@@ -357,6 +457,7 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
 #ifndef RT_SB
 #define RT_SB 2
 #endif
+template <int M>
 RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[RT_SB], const float dist[RT_SB], bool occ[RT_SB], Cnt& cnt) {
     bool act[RT_SB];
     cnt.rays += RT_SB;
@@ -402,6 +503,12 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     });
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
         const DMesh m = ldc(&sc.meshes[mi]);
+        if ((M & RT_M_BVH) && m.bvh_root >= 0) { /* large mesh: one BVH traversal per ray */
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j)
+                if (!occ[j] && act[j] && mesh_any<M>(sc, m, o, d[j], dist[j], cnt.stack)) occ[j] = true;
+            continue;
+        }
         for_each_record(sc.tris + m.first_tri, m.n_tris, [&](const DTri& tr, uint32_t) {
             f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
             f3 sv = o - ld3(tr.v0);
@@ -455,7 +562,7 @@ RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
 }
 
 /* ---- Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276) ------------------ */
-template <bool KD>
+template <int M>
 RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     ++cnt.nodes;
     const DMaterial m = ldc(&sc.materials[material_index(sc, h.type, h.obj)]);
@@ -470,7 +577,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
         if (lt.type == RT_LIGHT_QUAD) {
             f3 sum = mk3(0.f, 0.f, 0.f);
             f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
-            if (!KD) {
+            if (!(M & RT_M_KD)) {
                 const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
                 for (int i0 = 0; i0 < 16; i0 += RT_SB) {
                     f3 L[RT_SB], Ld[RT_SB];
@@ -491,7 +598,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     for (int j = 0; j < RT_SB; ++j) { occ[j] = false; asm volatile("" ::"v"(Ld[j].x), "v"(dist[j])); }
                     cnt.rays += RT_SB;
 #else
-                    shadow_batch(sc, so, so_inside, Ld, dist, occ, cnt);
+                    shadow_batch<M>(sc, so, so_inside, Ld, dist, occ, cnt);
 #endif
 #pragma unroll
                     for (int j = 0; j < RT_SB; ++j)
@@ -509,7 +616,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                     f3 SP = S - P;
                     f3 L = norm3(SP);
-                    if (occluded<KD>(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
+                    if (occluded<M>(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
                     light_term(sum, lt, m, N, V, L);
                 }
             sum = sum / 16.f;
@@ -518,7 +625,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
         } else {
             f3 SP = ld3(lt.pos) - P;
             f3 L = norm3(SP);
-            if (occluded<KD>(sc, so, norm3(L), len3(SP), cnt)) continue;
+            if (occluded<M>(sc, so, norm3(L), len3(SP), cnt)) continue;
             light_term(diffuse, lt, m, N, V, L);
         }
     }
@@ -535,18 +642,18 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
  *   kind 3 glass, reflected child running, no refracted ray (total internal reflection)
  *   kind 4 glass, refracted child running : a = reflected colour */
 #define RT_MAX_BOUNCES 10
-template <bool KD>
+template <int M>
 RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
     float stk[RT_MAX_BOUNCES][8];
     int sp = 0;
     f3 ret = mk3(0.f, 0.f, 0.f);
     for (;;) {
-        HitRec rec = closest_rec<KD>(sc, o, d, cnt);
+        HitRec rec = closest_rec<M>(sc, o, d, cnt);
         bool descended = false;
         if (rec.type < 0) ret = mk3(0.f, 0.f, 0.f);
         else {
             FullHit h = finish_hit(sc, rec, o, d);
-            f3 col = shade<KD>(sc, h, rng, cnt);
+            f3 col = shade<M>(sc, h, rng, cnt);
             ret = col;
             if (sp < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
                 const DMaterial m = ldc(&sc.materials[ldc(&sc.spheres[h.obj].mat)]);

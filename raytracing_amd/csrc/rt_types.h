@@ -59,8 +59,20 @@ struct DTri {  /* 48 B: one Moller-Trumbore test reads exactly this */
 struct DMesh {  /* 32 B */
     uint32_t first_tri, n_tris;
     int32_t mat;
-    int32_t bvh_root;  /* index into bvh nodes, -1 = brute force over the triangle range */
+    int32_t bvh_root;  /* index into DeviceScene::bvh, -1 = brute force over the triangle range */
     int32_t pad[4];
+};
+
+/* Triangle BVH node (binary, 64 B = one cache-line half, four dwordx4 loads): the boxes of BOTH
+ * children, so one fetch decides which of them to visit.  Child k: n[k] == 0 -> inner node c[k];
+ * n[k] > 0 -> leaf = triangles [c[k], c[k] + n[k]) of DeviceScene::tris (global positions).
+ * Boxes are padded on the host; the reference has no such structure (Mesh::intersect is a
+ * brute-force loop, R/src/Mesh.h:225) -- it only has to visit every triangle the loop would accept. */
+struct DBvhNode {
+    float lo0[3]; int32_t c0;
+    float hi0[3]; int32_t n0;
+    float lo1[3]; int32_t c1;
+    float hi1[3]; int32_t n1;
 };
 
 /* Object-level kd-tree node, R/src/KDTree.h:12-29, children by index, leaf refs by range. */
@@ -75,7 +87,9 @@ struct DeviceScene {
     const DSphere* spheres;
     const DSquare* squares;
     const DMesh* meshes;
-    const DTri* tris;
+    const DTri* tris;           /* per mesh: original order (brute force) or BVH leaf order */
+    const uint32_t* tri_orig;   /* mesh-local original index of tris[i]: tIndex and the tie-break */
+    const DBvhNode* bvh;
     const float* normals;  /* xyz per vertex */
     const DMaterial* materials;
     const DLight* lights;
