@@ -275,3 +275,31 @@ def test_bvh_scene_intersect_and_trace():
     ok = np.isfinite(img_o) & np.isfinite(img_g)
     assert np.abs(img_o[ok] - img_g[ok]).max() <= 5e-6
     g.close()
+
+
+def test_bvh_100k_triangles_spot_check(tmp_path):
+    """Full-size mesh (100 352 triangles, loaded from an OFF file by the host Mesh class): 1 500 rays against the
+    brute-force oracle (which needs ~1.5e8 triangle tests for them)."""
+    from raytracing_amd import host
+    from tools import make_mesh_off
+    off = str(tmp_path / "grid225.off")
+    p, t = make_mesh_off.make(225)
+    make_mesh_off.write_off(off, p, t)
+    hs = host.HostScene.mesh_file(off, with_spheres=True)
+    assert hs.desc.n_triangles == 100352
+    o = orc.Scene.from_desc(api.copy_struct(orc.SceneDesc, hs.desc), keep=hs)
+    g = hs.upload()
+    org, d = rayset.primary_grid(orc, 40, 25, seed=3)
+    o2, d2 = rayset.interior_rays(300, seed=5)
+    verts = np.ctypeslib.as_array(hs.desc.positions, shape=(hs.desc.n_vertices, 3))
+    rng = np.random.default_rng(8)
+    o3 = rng.uniform(-1.8, 1.8, (700, 3)).astype(np.float32)
+    o3[:, 1] = rng.uniform(-0.5, 1.8, 700).astype(np.float32)
+    d3 = (verts[rng.integers(0, len(verts), 700)] + rng.normal(scale=0.01, size=(700, 3)).astype(np.float32) - o3).astype(np.float32)
+    org, d = np.concatenate([org, o2, o3]), np.concatenate([d, d2, d3])
+    a, b = o.intersect(org, d), g.intersect(org, d)
+    assert (a["type"][a["hit"] == 1] == 0).sum() > 400
+    bad = _grazing_report(a, b)
+    assert bad.size == 0, f"{bad.size} grazing mismatches: {bad[:8]}"
+    assert_hits_equal(a, b, "100k mesh")
+    g.close()
