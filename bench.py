@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=3, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--flop-per-ray", type=float, default=0.0, help="override instead of counting on the CPU")
     args = ap.parse_args()
 

@@ -60,8 +60,13 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     }
 }
 
+#ifdef RT_WAVES_PER_EU
+#define RT_OCC __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+#else
+#define RT_OCC
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
+__global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);

@@ -535,7 +535,11 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
 struct Rng {
     uint32_t key, k;
     /* (float)rand() / RAND_MAX with RAND_MAX converted to float = 2^31 (R/src/Scene.h:259-260) */
+#if defined(RT_ABLATE) && (RT_ABLATE & 8)
+    RT_DEV float unit() { key = key * 1664525u + 1013904223u; ++k; return (float)(int)(key >> 1) / 2147483648.f; }
+#else
     RT_DEV float unit() { return (float)(int)rt_rand31(key, k++) / 2147483648.f; }
+#endif
 };
 
 /* powf(x, y) for x >= 0 through double: x^16 (the Cornell shininess) by four exact-enough double
@@ -591,7 +595,11 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                         f3 SP = S - P;
                         L[j] = norm3(SP);
+#if defined(RT_ABLATE) && (RT_ABLATE & 4)
+                        Ld[j] = L[j];
+#else
                         Ld[j] = norm3(L[j]); /* Ray() normalises L again */
+#endif
                         dist[j] = len3(SP);
                     }
 #if defined(RT_ABLATE) && (RT_ABLATE & 1)
