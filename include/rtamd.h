@@ -181,6 +181,12 @@ int rt_init(int device);
 int rt_shutdown(void);
 const char* rt_last_error(void);
 
+/* Device self-test of the library's shortened divide / sqrt sequences: normalises `n` pseudo-random
+ * vectors (components with random signs, mantissas and exponents in [2^-44, 2^44], i.e. across and
+ * beyond the range the fast path accepts) both ways and counts results whose bits differ from the
+ * IEEE operators `/` and sqrt.  *mismatches must come back 0.  No reference counterpart. */
+int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches);
+
 /* ---- scene -------------------------------------------------------------------------------- */
 /* Copy the scene, build the object-level kd-tree (R/src/KDTree.cpp:363-519, done on the host as
  * Scene::buildKDTree does) and the per-mesh triangle BVH, upload everything.  Stands in for the

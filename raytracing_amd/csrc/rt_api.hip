@@ -180,6 +180,28 @@ __global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __re
     dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
 }
 
+/* normalisation through the shortened sequences vs through the IEEE operators, on random vectors */
+__global__ __launch_bounds__(256) void k_selftest_arith(uint64_t n, uint32_t seed, unsigned long long* mismatches) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t key = rt_rng_key(seed, (uint32_t)i, (uint32_t)(i >> 32));
+    float c[3];
+    for (int a = 0; a < 3; ++a) {
+        uint32_t m = rt_mix32(key + 2 * a), e = rt_mix32(key + 2 * a + 1);
+        uint32_t bits = (m & 0x807fffffu) | ((127u - 44u + e % 89u) << 23); /* sign, mantissa, exponent 2^-44 .. 2^44 */
+        if ((e >> 8) % 97u == 0) bits &= 0x80000000u;                           /* now and then an exact zero */
+        c[a] = __int_as_float((int)bits);
+    }
+    f3 v = mk3(c[0], c[1], c[2]);
+    float L_fast, L_ref = __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    f3 f = norm3_len(v, L_fast);
+    f3 r = mk3(v.x / L_ref, v.y / L_ref, v.z / L_ref);
+    bool same = __float_as_int(L_fast) == __float_as_int(L_ref) && __float_as_int(f.x) == __float_as_int(r.x) &&
+                __float_as_int(f.y) == __float_as_int(r.y) && __float_as_int(f.z) == __float_as_int(r.z);
+    bool both_nan = (L_ref != L_ref) && (L_fast != L_fast);
+    if (!same && !both_nan) atomicAdd(mismatches, 1ull);
+}
+
 /* ======================================================================================== */
 /*                                       host state                                         */
 /* ======================================================================================== */
@@ -327,6 +349,25 @@ int rt_shutdown(void) {
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr; g.ev0 = g.ev1 = nullptr;
     g.ready = false; g.device = -1;
+    return RT_OK;
+}
+
+int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_selftest_arith: call rt_init first");
+    if (!mismatches) return fail(RT_E_INVALID, "rt_selftest_arith: null output");
+    if (n > (1ull << 38)) return fail(RT_E_LIMIT, "rt_selftest_arith: n too large");
+    *mismatches = 0;
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void* d_m;
+    int rc;
+    if ((rc = tmp.get(&d_m, 8))) return rc;
+    HIP_TRY(hipMemsetAsync(d_m, 0, 8, g.stream));
+    hipLaunchKernelGGL(k_selftest_arith, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, n, seed, (unsigned long long*)d_m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mismatches, d_m, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
     return RT_OK;
 }
 

@@ -36,7 +36,48 @@ RT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RT_DEV float len3(f3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-RT_DEV f3 norm3(f3 a) { float L = len3(a); return mk3(a.x / L, a.y / L, a.z / L); } /* R/src/Vec3.h:34 */
+
+/* ---- correctly rounded sqrt / divide without the range scaffolding --------------------------
+ * hipcc expands an IEEE fp32 divide into v_div_scale x2, v_rcp, two FMAs refining the reciprocal,
+ * a multiply, three FMAs correcting the quotient, v_div_fmas and v_div_fixup; an IEEE sqrt into a
+ * 2^32 pre-scale for tiny inputs, v_sqrt, a one-ulp-down / one-ulp-up residual test and a
+ * special-value select.  For operands in a "plain" range (|x| in [2^-40, 2^40] below) v_div_scale
+ * returns its input unscaled with VCC = 0, v_div_fmas is then an ordinary FMA, v_div_fixup passes
+ * the quotient through and the sqrt pre-scale is not taken -- so the helpers below run exactly the
+ * compiler's remaining instructions and return bit-identical results, while a normalisation
+ * shares one refined reciprocal between its three quotients.  Anything outside the range (zero,
+ * subnormal, huge, NaN components) takes the ordinary operators. */
+RT_DEV float sqrt_plain(float x) { /* x in [2^-96, FLT_MAX] */
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+    float e_dn = __builtin_fmaf(-s_dn, s, x), e_up = __builtin_fmaf(-s_up, s, x);
+    s = (0.f >= e_dn) ? s_dn : s;
+    s = (0.f < e_up) ? s_up : s;
+    return s;
+}
+RT_DEV float rcp_refined(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+}
+RT_DEV float div_plain(float a, float b, float r) { /* r = rcp_refined(b) */
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+/* normalize() of R/src/Vec3.h:34: L = sqrt(x^2 + y^2 + z^2), three true divides by L; also returns L */
+RT_DEV f3 norm3_len(f3 a, float& L) {
+    float q = a.x * a.x + a.y * a.y + a.z * a.z;
+    float lo = fminf(fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    float hi = fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    if (lo >= 0x1p-40f && hi <= 0x1p40f) { /* every component plain => q, L and the quotients are too */
+        L = sqrt_plain(q);
+        float r = rcp_refined(L);
+        return mk3(div_plain(a.x, L, r), div_plain(a.y, L, r), div_plain(a.z, L, r));
+    }
+    L = __builtin_sqrtf(q);
+    return mk3(a.x / L, a.y / L, a.z / L);
+}
+RT_DEV f3 norm3(f3 a) { float L; return norm3_len(a, L); }
 RT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 RT_DEV float max_std(float a, float b) { return (a < b) ? b : a; } /* std::max, NaN behaviour included */
 RT_DEV float min_std(float a, float b) { return (b < a) ? b : a; } /* std::min */
@@ -594,13 +635,12 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
                         f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                         f3 SP = S - P;
-                        L[j] = norm3(SP);
+                        L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
 #if defined(RT_ABLATE) && (RT_ABLATE & 4)
                         Ld[j] = L[j];
 #else
                         Ld[j] = norm3(L[j]); /* Ray() normalises L again */
 #endif
-                        dist[j] = len3(SP);
                     }
 #if defined(RT_ABLATE) && (RT_ABLATE & 1)
                     for (int j = 0; j < RT_SB; ++j) { occ[j] = false; asm volatile("" ::"v"(Ld[j].x), "v"(dist[j])); }

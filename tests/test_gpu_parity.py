@@ -303,3 +303,9 @@ def test_bvh_100k_triangles_spot_check(tmp_path):
     assert bad.size == 0, f"{bad.size} grazing mismatches: {bad[:8]}"
     assert_hits_equal(a, b, "100k mesh")
     g.close()
+
+
+def test_shortened_divide_and_sqrt_equal_the_ieee_operators():
+    """2^28 random vectors (exponents 2^-44 .. 2^44, zeros mixed in): the fast normalisation path must
+    return the bits of sqrt and `/` everywhere, inside and outside the range it accepts."""
+    assert api.selftest_arith(1 << 28, seed=7) == 0
