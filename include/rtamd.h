@@ -201,11 +201,16 @@ int rt_scene_kdtree(rt_scene_t scene, int32_t* nodes, uint32_t* n_nodes, int32_t
                     uint32_t* n_refs, float root_box[6]);
 
 /* ---- batch closest hit: Scene::computeIntersection (R/src/Scene.h:169-205) over n rays ------
- * org/dir: 3*n floats.  dir is normalised by the callee the way the Ray constructor does
- * (R/src/Line.h:13-16), so pass what the reference passes to Ray(o, d). */
+ * org/dir: 3*n floats = origin() and direction() of the reference's Ray objects: the Ray constructor has
+ * already normalised the direction (R/src/Line.h:13-16) and the callee does not normalise again.
+ * rt_normalize_dirs applies that constructor's normalisation to raw directions. */
 int rt_intersect(rt_scene_t scene, const float* org, const float* dir, size_t n, rt_hit* out);
 int rt_intersect_device(rt_scene_t scene, const float* d_org, const float* d_dir, size_t n,
                         rt_hit* d_out, void* hip_stream);
+
+/* d[i] /= |d[i]| exactly as Line's constructor computes it (sqrt of the left-to-right sum of squares, three
+ * true divides).  Host arithmetic, in place allowed (out == dir). */
+void rt_normalize_dirs(const float* dir, size_t n, float* out);
 
 /* ---- batch Mesh::intersect (R/src/Mesh.h:206-281) of mesh `mesh` alone: exposes tIndex ------ */
 int rt_mesh_intersect(rt_scene_t scene, uint32_t mesh, const float* org, const float* dir,
@@ -217,8 +222,9 @@ int rt_generate_rays(const rt_camera* cam, const float* u, const float* v, size_
                      float* dir);
 
 /* ---- batch Scene::rayTrace (R/src/Scene.h:716-720) under the counter RNG -------------------
- * Ray i is traced as sample (pixel[i], sample[i]); its rand() calls start at index k0 (2 when the
- * two jitter draws of R/main.cpp:186-187 precede it, 0 otherwise).  rgb: 3*n floats. */
+ * Ray i (origin / unit direction as for rt_intersect) is traced as sample (pixel[i], sample[i]); its rand()
+ * calls start at index k0 (2 when the two jitter draws of R/main.cpp:186-187 precede it, 0 otherwise).
+ * rgb: 3*n floats. */
 int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, const uint32_t* pixel,
              const uint32_t* sample, uint32_t seed, uint32_t k0, float* rgb, rt_stats* stats);
 

@@ -98,6 +98,7 @@ def lib():
         L.orc_camera_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera)]
         L.orc_camera_build.argtypes = [C.c_float] * 3 + [C.c_uint32] * 2 + [C.c_float] * 4 + [fp, C.POINTER(Camera)]
         L.orc_generate_rays.argtypes = [C.POINTER(Camera), vp, vp, C.c_size_t, vp, vp]
+        L.orc_normalize_dirs.argtypes = [vp, C.c_size_t, vp]
         L.orc_intersect.argtypes = [vp, vp, vp, C.c_size_t, vp]
         L.orc_mesh_intersect.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, vp]
         L.orc_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(Stats)]
@@ -219,6 +220,14 @@ def generate_rays(cam, u, v):
     dirs = np.zeros((n, 3), np.float32)
     lib().orc_generate_rays(C.byref(cam), _ptr(u), _ptr(v), n, _ptr(org), _ptr(dirs))
     return org, dirs
+
+
+def normalize_dirs(dirs):
+    """Ray-constructor normalisation of raw directions (float32, the reference's operation order)."""
+    dirs = _f32(dirs)
+    out = np.zeros_like(dirs)
+    lib().orc_normalize_dirs(_ptr(dirs), dirs.shape[0], _ptr(out))
+    return out
 
 
 def quantize(rgb):

@@ -234,6 +234,8 @@ void kd_build_scene(OScene& s) {
 struct Ray { /* R/src/Line.h:13-16 + R/src/Ray.h: the constructor normalises the direction */
     V3 o, d;
     Ray(const V3& o_, const V3& d_) : o(o_), d(d_) { normalize(d); }
+    /* a Ray that already exists: origin() and direction() as the constructor left them */
+    static Ray stored(const V3& o_, const V3& d_) { Ray r(o_, V3(1.f, 0.f, 0.f)); r.d = d_; return r; }
 };
 
 struct Hit { /* R/src/Hit.h + the fields of rt_hit */
@@ -960,10 +962,20 @@ void orc_generate_rays(const rt_camera* cam, const float* u, const float* v, siz
     }
 }
 
+/* Line's constructor normalisation (R/src/Line.h:13-16) applied to raw directions */
+void orc_normalize_dirs(const float* dir, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        V3 d = from3(dir + 3 * i);
+        normalize(d);
+        for (int a = 0; a < 3; ++a) out[3 * i + a] = d[a];
+    }
+}
+
+/* org / dir below are origin() / direction() of existing Ray objects (direction already unit length) */
 void orc_intersect(orc_scene* h, const float* org, const float* dir, size_t n, rt_hit* out) {
     Counters c;
     for (size_t i = 0; i < n; ++i) {
-        Ray r(from3(org + 3 * i), from3(dir + 3 * i));
+        Ray r = Ray::stored(from3(org + 3 * i), from3(dir + 3 * i));
         fill_hit(out[i], closest_hit(h->s, r, c));
     }
     h->total += c;
@@ -972,7 +984,7 @@ void orc_intersect(orc_scene* h, const float* org, const float* dir, size_t n, r
 void orc_mesh_intersect(orc_scene* h, uint32_t mesh, const float* org, const float* dir, size_t n, rt_hit* out) {
     Counters c;
     for (size_t i = 0; i < n; ++i) {
-        Ray r(from3(org + 3 * i), from3(dir + 3 * i));
+        Ray r = Ray::stored(from3(org + 3 * i), from3(dir + 3 * i));
         Hit hit;
         if (mesh_hit(h->s, h->s.meshes[mesh], r, hit, c)) { hit.type = RT_MESH; hit.object = (int)mesh; }
         fill_hit(out[i], hit);
@@ -986,7 +998,7 @@ void orc_trace(orc_scene* h, const float* org, const float* dir, size_t n, const
         Rng rng;
         rng.key = rt_rng_key(seed, pixel[i], sample[i]);
         rng.k = k0;
-        Ray r(from3(org + 3 * i), from3(dir + 3 * i));
+        Ray r = Ray::stored(from3(org + 3 * i), from3(dir + 3 * i));
         V3 col = trace(h->s, r, 10, rng, c); /* Scene::rayTrace, Scene.h:716-720 */
         ++c.samples;
         for (int a = 0; a < 3; ++a) rgb[3 * i + a] = col[a];

@@ -14,6 +14,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
-    f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
+    f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
     HitRec rec = closest_rec<M>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
                                                         const float* __restrict__ dir, size_t n, rt_hit* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
+    f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
     HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     const DMesh m = ldc(&sc.meshes[mesh]);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __re
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
     uint32_t smp = 0;
     if (i < n) {
-        f3 o = ld3(org + 3 * i), d = norm3(ld3(dir + 3 * i));
+        f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
         Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
         f3 c = trace_path<M>(sc, o, d, rng, cnt);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
@@ -552,6 +553,14 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
     }
     return RT_OK;
+}
+
+void rt_normalize_dirs(const float* dir, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        float x = dir[3 * i], y = dir[3 * i + 1], z = dir[3 * i + 2];
+        float L = std::sqrt(x * x + y * y + z * z);
+        out[3 * i] = x / L; out[3 * i + 1] = y / L; out[3 * i + 2] = z / L;
+    }
 }
 
 void rt_counters_total(const uint64_t* h, uint64_t out3[3]) {

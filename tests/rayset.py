@@ -53,6 +53,7 @@ def sphere_surface_rays(center, radius, n, seed=19):
 
 
 def mixed(orc, n_each=4000):
+    """(origins, unit directions) as the fields of reference Ray objects."""
     parts = [primary_grid(orc, 96, 54), interior_rays(n_each), outside_rays(n_each), axis_rays(n_each),
              sphere_surface_rays((-1.0, -1.25, -0.5), 0.75, n_each), sphere_surface_rays((1.0, -1.25, 0.5), 0.75, n_each)]
-    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    return np.concatenate([p[0] for p in parts]), orc.normalize_dirs(np.concatenate([p[1] for p in parts]))

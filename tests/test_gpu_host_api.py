@@ -1,0 +1,75 @@
+"""GPU tests of the C++ host layer as a drop-in: the reference-style single-ray calls
+(Scene::computeIntersection, Scene::rayTrace, Mesh::intersect) and the headless '+' / 'r' driver, each
+compared with the CPU oracle.  The C++ programs are built by raytracing_amd/host/Makefile."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracing_amd import host
+from tests import rayset
+
+pytestmark = pytest.mark.gpu
+HOST_DIR = os.path.join(os.path.dirname(os.path.abspath(host.__file__)), "host")
+
+
+def _hexf(tok):
+    return np.float32(float.fromhex(tok)) if tok not in ("nan", "-nan", "inf", "-inf") else np.float32(tok)
+
+
+@pytest.mark.parametrize("sid", [2, 3])
+def test_single_ray_calls_match_oracle(sid, tmp_path):
+    org, d = rayset.primary_grid(orc, 12, 10, seed=sid)
+    o2, d2 = rayset.interior_rays(60, seed=sid + 40)
+    org, d = np.concatenate([org, o2]), np.concatenate([d, d2])
+    n = len(org)
+    pix = np.arange(n, dtype=np.uint32) * 7
+    smp = np.arange(n, dtype=np.uint32) % 5
+    rays = tmp_path / "rays.txt"
+    with open(rays, "w") as f:
+        for i in range(n):
+            f.write(" ".join(repr(float(x)) for x in (*org[i], *d[i])) + f" {pix[i]} {smp[i]}\n")
+    out = subprocess.run([os.path.join(HOST_DIR, "api_check"), str(sid), host.STAR_OFF, str(rays)], check=True,
+                         capture_output=True, text=True, timeout=300).stdout
+    lines = [ln for ln in out.splitlines() if "|" in ln]
+    assert len(lines) == n
+    o = orc.Scene.builtin(sid)
+    du = orc.normalize_dirs(d)  # what the Ray objects built by api_check hold
+    hits = o.intersect(org, du)
+    cols, _ = o.trace(org, du, pix, smp, seed=1, k0=2)
+    mh = o.mesh_intersect(0, org, du) if sid == 3 else None
+    for i, ln in enumerate(lines):
+        parts = [p.split() for p in ln.split("|")]
+        a = parts[0]
+        assert int(a[0]) == hits["hit"][i] and int(a[1]) == hits["type"][i] and int(a[2]) == hits["object"][i]
+        if hits["hit"][i]:
+            got = np.array([_hexf(t) for t in a[3:10]], np.float32)
+            want = np.concatenate([[hits["t"][i]], hits["p"][i], hits["n"][i]]).astype(np.float32)
+            assert got.tobytes() == want.tobytes(), (i, got, want)
+        c = np.array([_hexf(t) for t in parts[1]], np.float32)
+        assert np.abs(c - cols[i]).max() <= 2e-6
+        if mh is not None:
+            m = parts[2]
+            assert int(m[0]) == mh["hit"][i]
+            if mh["hit"][i]:
+                assert int(m[1]) == mh["tri"][i] and _hexf(m[2]).tobytes() == mh["t"][i].tobytes()
+                w = np.array([_hexf(t) for t in m[3:6]], np.float32)
+                assert w[1].tobytes() == mh["u"][i].tobytes() and w[2].tobytes() == mh["v"][i].tobytes()
+
+
+def test_headless_plus_and_r_keys(tmp_path):
+    """rt_main --keys +r : '+' selects scene 3, 'r' renders it to a P3 file; same bytes as the oracle's render
+    of that scene under the counter RNG (up to the rare pixel whose colour sits on a quantisation step)."""
+    out = tmp_path / "rendu.ppm"
+    w, h, spp = 96, 80, 3
+    subprocess.run([os.path.join(HOST_DIR, "rt_main"), "--w", str(w), "--h", str(h), "--spp", str(spp), "--seed", "1", "--keys", "+r",
+                    "--out", str(out), "--off", host.STAR_OFF], check=True, capture_output=True, timeout=300)
+    toks = open(out).read().split()
+    assert toks[:4] == ["P3", str(w), str(h), "255"]
+    got = np.array(toks[4:], np.uint8).reshape(h, w, 3)
+    o = orc.Scene.builtin(3)
+    img, _ = o.render(orc.camera_default(w, h), w, h, spp, orc.RT_RNG_COUNTER, seed=1, threads=4)
+    want = orc.quantize(img)
+    assert (got != want).mean() < 1e-3 and np.abs(got.astype(int) - want.astype(int)).max() <= 1

@@ -82,7 +82,7 @@ def test_mesh_intersect_tindex():
     g = api.DeviceScene(o.desc, keep=o)
     org, d = rayset.interior_rays(20000, seed=23)
     tgt = np.random.default_rng(5).uniform(-0.6, 0.6, (20000, 3)).astype(np.float32) + np.float32([0, -1.3, 0])
-    d = (tgt - org).astype(np.float32)
+    d = orc.normalize_dirs((tgt - org).astype(np.float32))
     a = o.mesh_intersect(0, org, d)
     b = g.mesh_intersect(0, org, d)
     assert a["hit"].sum() > 2000 and len(np.unique(a["tri"][a["hit"] == 1])) == 24
@@ -120,6 +120,7 @@ def test_trace_per_sample_colors(scene_pair):
     u = ((np.repeat(xs.ravel(), spp) + rng.random(pix.size)) / w).astype(np.float32)
     v = ((np.repeat(ys.ravel(), spp) + rng.random(pix.size)) / h).astype(np.float32)
     org, d = orc.generate_rays(orc.camera_default(w, h), u, v)
+    d = orc.normalize_dirs(d)  # Ray(pos, dir) normalises the already-unit direction once more (R/main.cpp:190)
     oc, ost = o.trace(org, d, pix, smp, seed=1, k0=2)
     gc, gst = g.trace(org, d, pix, smp, seed=1, k0=2)
     assert (ost.rays, ost.samples, ost.nodes) == (gst.rays, gst.samples, gst.nodes)
@@ -217,6 +218,7 @@ def test_kd_internal_nodes_trace(kd_pair):
     u = ((np.repeat(xs.ravel(), spp) + rng.random(pix.size)) / w).astype(np.float32)
     v = ((np.repeat(ys.ravel(), spp) + rng.random(pix.size)) / h).astype(np.float32)
     org, d = orc.generate_rays(orc.camera_default(w, h), u, v)
+    d = orc.normalize_dirs(d)
     oc, ost = o.trace(org, d, pix, smp, seed=2, k0=2)
     gc, gst = g.trace(org, d, pix, smp, seed=2, k0=2)
     assert (ost.rays, ost.samples, ost.nodes) == (gst.rays, gst.samples, gst.nodes)
@@ -252,6 +254,7 @@ def test_bvh_mesh_intersect_matches_brute_force():
     tgt = pos[rng.integers(0, len(pos), n)] + rng.normal(scale=0.05, size=(n, 3)).astype(np.float32)
     d = (tgt - org).astype(np.float32)
     d[: n // 10] = rng.normal(size=(n // 10, 3)).astype(np.float32)     # and some that mostly miss
+    d = orc.normalize_dirs(d)
     a = o.mesh_intersect(0, org, d)
     b = g.mesh_intersect(0, org, d)
     assert a["hit"].sum() > n // 2
@@ -296,7 +299,7 @@ def test_bvh_100k_triangles_spot_check(tmp_path):
     o3 = rng.uniform(-1.8, 1.8, (700, 3)).astype(np.float32)
     o3[:, 1] = rng.uniform(-0.5, 1.8, 700).astype(np.float32)
     d3 = (verts[rng.integers(0, len(verts), 700)] + rng.normal(scale=0.01, size=(700, 3)).astype(np.float32) - o3).astype(np.float32)
-    org, d = np.concatenate([org, o2, o3]), np.concatenate([d, d2, d3])
+    org, d = np.concatenate([org, o2, o3]), orc.normalize_dirs(np.concatenate([d, d2, d3]))
     a, b = o.intersect(org, d), g.intersect(org, d)
     assert (a["type"][a["hit"] == 1] == 0).sum() > 400
     bad = _grazing_report(a, b)
