@@ -276,9 +276,9 @@ RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
                 float t, u, v;
                 if (tri_t(ldc(&sc.tris[first + k]), o, d, t, u, v) && t > 1e-6f) {
                     if (ANY) { if (t < dist) return true; }
-                    else {
+                    else if (t <= best_t) { /* the original index is only needed to break a tie */
                         uint32_t orig = ldc(&sc.tri_orig[first + k]);
-                        if (t < best_t || (t == best_t && orig < best_orig)) {
+                        if (t < best_t || orig < best_orig) {
                             best_t = t; best_tri = first + k; best_u = u; best_v = v; best_orig = orig; found = true;
                         }
                     }
