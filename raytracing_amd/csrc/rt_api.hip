@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -66,17 +67,80 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
 #else
 #define RT_OCC
 #endif
+/* ---- launch order of the tiles: expensive tiles first -------------------------------------
+ * A pixel that looks into the glass sphere traces a tree of up to 2^11 rays per sample: its wave
+ * runs for ~1 ms, near the sphere's rim for more than 3 ms, where an ordinary one runs for ~45 us.
+ * When such a wave is handed out late it finishes alone after the rest of the grid (measured: one
+ * rim pixel started at 2 ms stretched a 4.2 ms launch of one eighth of the frame to 5.3 ms).  So
+ * before each render one wave per tile walks the path tree of the centre ray of every pixel of
+ * the tile without shading it, and the tiles are launched in the order of their deepest tree
+ * (capped at RT_PROBE_CAP nodes, where an ordinary glass pixel has 16-21; counting sort in k_tile_place).  The order only changes WHEN a
+ * tile is rendered: pixel values, RNG streams and the output layout depend on the tile id alone.
+ * Workspace (uint32): [0, K) tiles per key, [K, 2K) cursors, [2K, 2K+n) key of local tile i,
+ * [2K+n, 2K+2n) the order; K = RT_ORDER_KEYS. */
+#define RT_ORDER_KEYS (RT_PROBE_CAP + 1)
+template <int M>
+__global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
+    __shared__ uint32_t s_deepest;
+    const uint32_t local_tile = blockIdx.x; /* one workgroup per tile, one thread per pixel (a 16 x 16 tile) */
+    const uint32_t tile = rp.rank + local_tile * rp.world;
+    const uint32_t x0 = rt_tile_column(tile, rp.tiles_x) * rp.tile_w, y0 = (tile / rp.tiles_x) * rp.tile_h;
+    if (threadIdx.x == 0) s_deepest = 0;
+    __syncthreads();
+    uint32_t deepest = 0;
+    for (uint32_t i = threadIdx.x; i < rp.tile_w * rp.tile_h; i += 256) {
+        const uint32_t x = x0 + i % rp.tile_w, y = y0 + i / rp.tile_w;
+        if (x >= rp.w || y >= rp.h) continue;
+        float u = ((float)(int)x + 0.5f) / (float)(int)rp.w;
+        float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
+        f3 o, d;
+        primary_ray(cam, u, v, &o, &d);
+        Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
+        Rng rng; rng.key = 0; rng.k = 0;
+        (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
+        deepest = max(deepest, cnt.nodes);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_deepest, deepest);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t key = (RT_ORDER_KEYS - 1) - min(s_deepest, (uint32_t)(RT_ORDER_KEYS - 1)); /* key 0 = deepest */
+        ws[2 * RT_ORDER_KEYS + local_tile] = key;
+        atomicAdd(&ws[key], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_place(uint32_t* __restrict__ ws, uint32_t n) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t key = ws[2 * RT_ORDER_KEYS + i], base = 0;
+    for (uint32_t k = 0; k < key; ++k) base += ws[k];
+    ws[2 * RT_ORDER_KEYS + n + base + atomicAdd(&ws[RT_ORDER_KEYS + key], 1u)] = i;
+}
+
+#ifdef RT_WAVE_TIMES /* debug build only: start / end clock of every wave of k_render */
+__device__ unsigned long long* rt_dbg_times;
+extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_times), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int M>
 __global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
-                                                uint64_t* __restrict__ counters) {
+                                                uint64_t* __restrict__ counters, const uint32_t* __restrict__ order) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
-    const uint32_t local_tile = wave / px_per_tile;
-    const bool wave_has_pixel = local_tile < rp.n_local_tiles; /* wave-uniform */
-    const uint32_t in_tile = wave - local_tile * px_per_tile;
+    const uint32_t slot = wave / px_per_tile; /* position in the launch order */
+    const bool wave_has_pixel = slot < rp.n_local_tiles; /* wave-uniform */
+    const uint32_t in_tile = wave - slot * px_per_tile;
+    const uint32_t local_tile = (order && wave_has_pixel) ? ldc(&order[slot]) : slot;
+#ifdef RT_WAVE_TIMES
+    const unsigned long long t_start = wall_clock64();
+#endif
     const uint32_t tile = rp.rank + local_tile * rp.world;
-    const uint32_t x = (tile % rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
+    const uint32_t x = rt_tile_column(tile, rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
     const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
     const bool in_image = wave_has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
@@ -107,6 +171,12 @@ __global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCa
     }
     acc = acc / (float)rp.spp; /* image /= nsamples */
     if (wave_has_pixel && lane == 0) { dst[0] = in_image ? acc.x : 0.f; dst[1] = in_image ? acc.y : 0.f; dst[2] = in_image ? acc.z : 0.f; }
+#ifdef RT_WAVE_TIMES
+    if (lane == 0 && rt_dbg_times) {
+        rt_dbg_times[3ull * wave] = t_start; rt_dbg_times[3ull * wave + 1] = wall_clock64();
+        rt_dbg_times[3ull * wave + 2] = ((unsigned long long)y << 32) | x;
+    }
+#endif
     flush_counters(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
 }
 
@@ -228,6 +298,7 @@ struct SceneRes {
 };
 
 const unsigned kCamSlots = 64;
+const unsigned kOrderSlots = 8;
 
 struct Lib {
     bool ready = false;
@@ -238,6 +309,13 @@ struct Lib {
      * (the kernel reads its camera through a pointer so the 2 x 16 doubles never occupy registers) */
     DCamera* cam_ring = nullptr;
     unsigned cam_next = 0;
+    rt_camera cam_last{};       /* the camera in slot cam_last_slot: an unchanged camera is not uploaded again */
+    int cam_last_slot = -1;
+    /* workspaces of k_tile_class / k_tile_place, one per render call in turn, grown on demand */
+    uint32_t* order_ws[kOrderSlots] = {};
+    size_t order_cap[kOrderSlots] = {};
+    unsigned order_next = 0;
+    bool order_tiles = true;    /* RTAMD_TILE_ORDER=0 renders the tiles in index order */
     std::map<rt_scene_t, SceneRes*> scenes;
     rt_scene_t next_handle = 1;
     std::string error;
@@ -332,6 +410,9 @@ int rt_init(int device) {
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipMalloc((void**)&g.cam_ring, kCamSlots * sizeof(DCamera)));
     g.cam_next = 0;
+    g.cam_last_slot = -1;
+    const char* ord = std::getenv("RTAMD_TILE_ORDER");
+    g.order_tiles = !(ord && ord[0] == '0');
     g.device = device;
     g.ready = true;
     return RT_OK;
@@ -345,6 +426,7 @@ int rt_shutdown(void) {
     g.scenes.clear();
     (void)hipFree(g.cam_ring);
     g.cam_ring = nullptr;
+    for (unsigned i = 0; i < kOrderSlots; ++i) { (void)hipFree(g.order_ws[i]); g.order_ws[i] = nullptr; g.order_cap[i] = 0; }
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
@@ -590,10 +672,35 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     if (rp.n_local_tiles == 0) return RT_OK;
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
     uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
-    DCamera* d_cam = g.cam_ring + (g.cam_next++ % kCamSlots);
-    HIP_TRY(hipMemcpyAsync(d_cam, &dc, sizeof(DCamera), hipMemcpyHostToDevice, st)); /* pageable source: staged before the call returns */
+    DCamera* d_cam;
+    if (g.cam_last_slot >= 0 && std::memcmp(&g.cam_last, cam, sizeof(rt_camera)) == 0) d_cam = g.cam_ring + g.cam_last_slot;
+    else {
+        /* a new camera goes to the next ring slot (never the one an earlier launch may still read);
+         * the copy source is pageable, so it is staged before the call returns */
+        g.cam_last_slot = (int)(g.cam_next++ % kCamSlots);
+        d_cam = g.cam_ring + g.cam_last_slot;
+        HIP_TRY(hipMemcpyAsync(d_cam, &dc, sizeof(DCamera), hipMemcpyHostToDevice, st));
+        g.cam_last = *cam;
+    }
+    const uint32_t* d_order = nullptr;
+    if (g.order_tiles && rp.n_local_tiles > 1) {
+        const unsigned slot = g.order_next++ % kOrderSlots;
+        const size_t words = 2 * RT_ORDER_KEYS + 2 * (size_t)rp.n_local_tiles;
+        if (g.order_cap[slot] < words) {
+            /* hipFree waits for the device, so no launch still reads the old block */
+            if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
+            HIP_TRY(hipMalloc((void**)&g.order_ws[slot], words * 4));
+            g.order_cap[slot] = words;
+        }
+        uint32_t* ws = g.order_ws[slot];
+        HIP_TRY(hipMemsetAsync(ws, 0, 2 * RT_ORDER_KEYS * 4, st));
+        RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws);
+        hipLaunchKernelGGL(k_tile_place, dim3(blocks_for(rp.n_local_tiles)), dim3(256), 0, st, ws, rp.n_local_tiles);
+        HIP_TRY(hipGetLastError());
+        d_order = ws + 2 * RT_ORDER_KEYS + rp.n_local_tiles;
+    }
     dim3 grid((unsigned)((waves + 3) / 4));
-    RT_DISPATCH(r->mode, k_render, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters);
+    RT_DISPATCH(r->mode, k_render, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -636,7 +743,7 @@ int rt_tiles_to_image(const float* gathered, uint32_t w, uint32_t h, uint32_t ti
     for (uint32_t t = 0; t < tiles_x * tiles_y; ++t) {
         uint32_t rank = t % world, local = t / world;
         const float* src = gathered + ((size_t)rank * per_rank + local) * tile_floats;
-        uint32_t x0 = (t % tiles_x) * tile_w, y0 = (t / tiles_x) * tile_h;
+        uint32_t x0 = rt_tile_column(t, tiles_x) * tile_w, y0 = (t / tiles_x) * tile_h;
         for (uint32_t yy = 0; yy < tile_h && y0 + yy < h; ++yy)
             for (uint32_t xx = 0; xx < tile_w && x0 + xx < w; ++xx)
                 std::memcpy(rgb_image + 3 * ((size_t)(y0 + yy) * w + x0 + xx), src + 3 * ((size_t)yy * tile_w + xx), 12);

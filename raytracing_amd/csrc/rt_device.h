@@ -688,9 +688,12 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
  *   kind 1 mirror : a = phong colour of the node, b = specular_material
  *   kind 2 glass, reflected child running : a = refracted origin, b = refracted direction
  *   kind 3 glass, reflected child running, no refracted ray (total internal reflection)
- *   kind 4 glass, refracted child running : a = reflected colour */
+ *   kind 4 glass, refracted child running : a = reflected colour
+ * PROBE = true walks the same tree without shading it (no light samples, no shadow rays) and only
+ * counts its nodes in cnt.nodes, up to RT_PROBE_CAP: the tree's shape does not depend on the shading. */
 #define RT_MAX_BOUNCES 10
-template <int M>
+#define RT_PROBE_CAP 24
+template <int M, bool PROBE = false>
 RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
     float stk[RT_MAX_BOUNCES][8];
     int sp = 0;
@@ -701,7 +704,9 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
         if (rec.type < 0) ret = mk3(0.f, 0.f, 0.f);
         else {
             FullHit h = finish_hit(sc, rec, o, d);
-            f3 col = shade<M>(sc, h, rng, cnt);
+            f3 col = mk3(0.f, 0.f, 0.f);
+            if (PROBE) { if (++cnt.nodes >= RT_PROBE_CAP) return ret; }
+            else col = shade<M>(sc, h, rng, cnt);
             ret = col;
             if (sp < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
                 const DMaterial m = ldc(&sc.materials[ldc(&sc.spheres[h.obj].mat)]);

@@ -62,7 +62,7 @@ class HostScene:
         return api.DeviceScene(self.desc, keep=self)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # module globals are gone at interpreter exit
             lib().rth_scene_free(self.h)
             self.h = None
 

@@ -1,5 +1,6 @@
 """Tile-sharded render across the GPUs of one node: one process per GPU (torch.distributed, backend
-nccl = RCCL over xGMI), the scene replicated on every GPU, tile t rendered by rank t % world, the
+nccl = RCCL over xGMI), the scene replicated on every GPU, tile t rendered by rank t % world (tile rows
+are rotated against each other, see tile_column, so a rank's tiles form diagonals), the
 tile buffers gathered on rank 0 and scattered into the row-major image.  The only exchange step is
 that gather (<= 25 MB for a 1080p float image in total); there is no data-path collective during the
 render itself.
@@ -25,6 +26,13 @@ class TileLayout:
         self.per_rank = (self.n_tiles + world - 1) // world  # rank 0 holds the most tiles
         self.tile_floats = tile_w * tile_h * 3
 
+    def tile_column(self, t):
+        """Column of tile t (rt_tile_column): row t // tiles_x is rotated by its own index."""
+        return (t % self.tiles_x + t // self.tiles_x) % self.tiles_x
+
+    def tile_origin(self, t):
+        return self.tile_column(t) * self.tw, (t // self.tiles_x) * self.th
+
     def local_tiles(self, rank):
         return (self.n_tiles + self.world - 1 - rank) // self.world
 
@@ -35,7 +43,8 @@ class TileLayout:
     def scatter_index(self):
         """For every image pixel (row-major) the index of its RGB triple in the rank-major gathered buffer."""
         ys, xs = np.mgrid[0:self.h, 0:self.w]
-        t = (ys // self.th) * self.tiles_x + (xs // self.tw)
+        ty = ys // self.th
+        t = ty * self.tiles_x + (xs // self.tw - ty) % self.tiles_x  # inverse of tile_column
         src = ((t % self.world) * self.per_rank + t // self.world) * (self.tw * self.th) + (ys % self.th) * self.tw + (xs % self.tw)
         return src.ravel().astype(np.int64)
 

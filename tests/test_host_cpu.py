@@ -79,7 +79,7 @@ def test_tiles_to_image_roundtrip():
     per = api.tiles_per_rank(w, h, tw, th, 0, world)
     buf = np.zeros((world, per, th, tw, 3), np.float32)
     for t in range(tx * ty):
-        x0, y0 = (t % tx) * tw, (t // tx) * th
+        x0, y0 = ((t % tx + t // tx) % tx) * tw, (t // tx) * th  # row t // tx is rotated by its index
         blk = img[y0:y0 + th, x0:x0 + tw]
         buf[t % world, t // world, :blk.shape[0], :blk.shape[1]] = blk
     out = api.tiles_to_image(buf.reshape(world, -1), w, h, tw, th, world)

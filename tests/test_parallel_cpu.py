@@ -28,7 +28,7 @@ def fake_render_fn(w, h, tw, th):
         full = expected_image(w, h)
         for j in range(lay.local_tiles(rank)):
             t = rank + j * world
-            x0, y0 = (t % lay.tiles_x) * tw, (t // lay.tiles_x) * th
+            x0, y0 = lay.tile_origin(t)
             blk = full[y0:y0 + th, x0:x0 + tw]
             buf[j, :blk.shape[0], :blk.shape[1]] = blk
         out.copy_(torch.from_numpy(buf.ravel()))
