@@ -76,8 +76,7 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
  * the tile without shading it, and the tiles are launched in the order of their deepest tree
  * (capped at RT_PROBE_CAP nodes, where an ordinary glass pixel has 16-21; counting sort in k_tile_place).  The order only changes WHEN a
  * tile is rendered: pixel values, RNG streams and the output layout depend on the tile id alone.
- * Workspace (uint32): [0, K) tiles per key, [K, 2K) cursors, [2K, 2K+n) key of local tile i,
- * [2K+n, 2K+2n) the order; K = RT_ORDER_KEYS. */
+ * Workspace (uint32): [0, n) key of local tile i (0 = deepest), [n, 2n) the order. */
 #define RT_ORDER_KEYS (RT_PROBE_CAP + 1)
 template <int M>
 __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws) {
@@ -107,17 +106,24 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t key = (RT_ORDER_KEYS - 1) - min(s_deepest, (uint32_t)(RT_ORDER_KEYS - 1)); /* key 0 = deepest */
-        ws[2 * RT_ORDER_KEYS + local_tile] = key;
-        atomicAdd(&ws[key], 1u);
+        ws[local_tile] = key;
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile_place(uint32_t* __restrict__ ws, uint32_t n) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    uint32_t key = ws[2 * RT_ORDER_KEYS + i], base = 0;
-    for (uint32_t k = 0; k < key; ++k) base += ws[k];
-    ws[2 * RT_ORDER_KEYS + n + base + atomicAdd(&ws[RT_ORDER_KEYS + key], 1u)] = i;
+/* One workgroup: histogram of the keys, exclusive scan, placement, all with LDS atomics (a
+ * grid-wide version spends 80 us on 8100 global atomics to two or three addresses). */
+__global__ __launch_bounds__(1024) void k_tile_place(uint32_t* __restrict__ ws, uint32_t n) {
+    __shared__ uint32_t s_count[RT_ORDER_KEYS], s_cursor[RT_ORDER_KEYS];
+    if (threadIdx.x < RT_ORDER_KEYS) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_count[ws[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < RT_ORDER_KEYS; ++k) { s_cursor[k] = run; run += s_count[k]; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) ws[n + atomicAdd(&s_cursor[ws[i]], 1u)] = i;
 }
 
 #ifdef RT_WAVE_TIMES /* debug build only: start / end clock of every wave of k_render */
@@ -685,7 +691,7 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     const uint32_t* d_order = nullptr;
     if (g.order_tiles && rp.n_local_tiles > 1) {
         const unsigned slot = g.order_next++ % kOrderSlots;
-        const size_t words = 2 * RT_ORDER_KEYS + 2 * (size_t)rp.n_local_tiles;
+        const size_t words = 2 * (size_t)rp.n_local_tiles;
         if (g.order_cap[slot] < words) {
             /* hipFree waits for the device, so no launch still reads the old block */
             if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
@@ -693,11 +699,10 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
             g.order_cap[slot] = words;
         }
         uint32_t* ws = g.order_ws[slot];
-        HIP_TRY(hipMemsetAsync(ws, 0, 2 * RT_ORDER_KEYS * 4, st));
         RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws);
-        hipLaunchKernelGGL(k_tile_place, dim3(blocks_for(rp.n_local_tiles)), dim3(256), 0, st, ws, rp.n_local_tiles);
+        hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
         HIP_TRY(hipGetLastError());
-        d_order = ws + 2 * RT_ORDER_KEYS + rp.n_local_tiles;
+        d_order = ws + rp.n_local_tiles;
     }
     dim3 grid((unsigned)((waves + 3) / 4));
     RT_DISPATCH(r->mode, k_render, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order);

@@ -64,7 +64,9 @@ class ShardedRenderer:
         self.perm = None
         if self.rank == 0:
             if self.world > 1:
-                self.gathered = [torch.empty_like(self.mine) for _ in range(self.world)]
+                # one block, rank-major: the gather writes into its slices, no concatenation afterwards
+                self.gathered_flat = torch.empty(self.world * self.mine.numel(), dtype=torch.float32, device=device)
+                self.gathered = list(self.gathered_flat.chunk(self.world))
             self.image = torch.zeros(h * w * 3, dtype=torch.float32, device=device)
             self.perm = torch.from_numpy(self.layout.scatter_index()).to(device)
 
@@ -76,7 +78,7 @@ class ShardedRenderer:
             dist.gather(self.mine, self.gathered, dst=0)
             if self.rank != 0:
                 return None
-            src = torch.cat(self.gathered)
+            src = self.gathered_flat
         else:
             src = self.mine
         torch.index_select(src.view(-1, 3), 0, self.perm, out=self.image.view(-1, 3))

@@ -166,6 +166,36 @@ def test_tile_sharding_is_exact():
     g.close()
 
 
+def test_tile_launch_order_does_not_change_the_image(tmp_path):
+    """The deepest-path-first launch order of the tiles only decides when a tile is rendered: a second
+    process with RTAMD_TILE_ORDER=0 (index order) produces the same floats, sharded or not."""
+    import subprocess
+    import sys
+    w, h, spp, tw, th = 200, 120, 3, 16, 16
+    out = tmp_path / "plain.npz"
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from raytracing_amd import api, host\n"
+        "api.init(0)\n"
+        "g = host.HostScene.builtin(2).upload()\n"
+        f"cam = host.camera_default({w}, {h})\n"
+        f"full, _ = g.render(cam, {w}, {h}, {spp}, seed=3, tile_w={tw}, tile_h={th})\n"
+        f"part, _ = g.render_tiles(cam, {w}, {h}, {spp}, 3, {tw}, {th}, 1, 3)\n"
+        f"np.savez({str(out)!r}, full=full, part=part)\n")
+    env = dict(os.environ, RTAMD_TILE_ORDER="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=100)
+    from raytracing_amd import host
+    g = host.HostScene.builtin(2).upload()
+    cam = host.camera_default(w, h)
+    full, _ = g.render(cam, w, h, spp, seed=3, tile_w=tw, tile_h=th)
+    part, _ = g.render_tiles(cam, w, h, spp, 3, tw, th, 1, 3)
+    ref = np.load(out)
+    assert np.array_equal(_bits(full), _bits(ref["full"])) and np.array_equal(_bits(part), _bits(ref["part"]))
+    assert full.mean() > 0.05
+    g.close()
+
+
 def test_scene3_matches_reference_render_statistically(golden_dir):
     """The GPU render of scene 3 (50 spp, counter RNG) against the reference's own rendu.ppm: different
     random numbers, same estimator, so the images agree up to Monte-Carlo noise."""

@@ -26,10 +26,9 @@ if a.ms and "GRBM_GUI_ACTIVE" in c:
     clk = c["GRBM_GUI_ACTIVE"] / 8 / (a.ms * 1e-3)
     print(f"shader clock                       : {clk / 1e9:.2f} GHz")
     simd_cycles = clk * a.ms * 1e-3 * 1024
-    if "SQ_ACTIVE_INST_VALU" in c:
-        print(f"VALU busy (SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * cycles)) : {c['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles * 100:.1f} %")
     if "SQ_INSTS_VALU" in c:
-        print(f"VALU issue floor (2 cycles per wave64 instruction)        : {c['SQ_INSTS_VALU'] * 2 / simd_cycles * 100:.1f} %")
+        # a SIMD issues one wave64 VALU instruction per 2 cycles at best (measured with tools/ubench/valu_rate.hip)
+        print(f"VALU issue-slot utilisation (SQ_INSTS_VALU * 2 cycles / (1024 SIMDs * cycles)) : {c['SQ_INSTS_VALU'] * 2 / simd_cycles * 100:.1f} %")
 if "SQ_WAVE_CYCLES" in c:
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in c:
