@@ -250,6 +250,16 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
 int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp,
                      uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
                      uint32_t world, float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
+/* One pass of a progressive render: samples [sample0, sample0 + spp_pass) of the spp_total the finished
+ * image has.  d_rgb_tiles carries the running float sum of R/main.cpp:191 between passes (pass 0 writes
+ * it, later passes continue it in sample order, the pass that reaches spp_total divides by spp_total as
+ * R/main.cpp:193 does), so any split into passes yields the floats of rt_render_device(spp_total).
+ * Between passes the buffer holds sums: divide by the samples so far to display it.
+ * rt_render_device(.., spp, ..) = rt_render_pass_device(.., spp, 0, spp, ..). */
+int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h,
+                          uint32_t spp_pass, uint32_t sample0, uint32_t spp_total, uint32_t seed,
+                          uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
+                          float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
 /* d_counters: NULL, or a zeroed device buffer of RT_COUNTER_WORDS uint64 (see above).  Host helper:
  * totals {rays, samples, nodes} of a counter buffer copied back to the host. */
 void rt_counters_total(const uint64_t* h_counters, uint64_t out3[3]);

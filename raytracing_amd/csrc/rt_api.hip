@@ -32,7 +32,8 @@
 struct RenderParams {
     uint32_t w, h, spp, seed;
     uint32_t tile_w, tile_h, tiles_x, n_tiles;
-    uint32_t rank, world, n_local_tiles, pad;
+    uint32_t rank, world, n_local_tiles, sample0; /* first sample of this pass */
+    uint32_t spp_total, pad[3];                   /* samples per pixel of the finished image */
 };
 
 /* sum of a per-lane counter over the wave, in every lane */
@@ -132,51 +133,83 @@ extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_times), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : -1;
 }
 #endif
-template <int M>
+/* One pass of the render: samples [sample0, sample0 + spp) of every pixel of this rank's tiles.
+ * The tile buffer carries image[x + y*w] of R/main.cpp:191 between passes: a pass with sample0 > 0
+ * continues the float sum it finds there, in sample order, and the pass that reaches spp_total
+ * divides (R/main.cpp:193) -- so k passes give the floats of one pass over all samples.
+ * PACK = false: one pixel per wave, lane = sample of a 64-sample chunk (spp > 32).
+ * PACK = true : spp <= 32, 64 / spp pixels per wave, lane = (pixel, sample), so that few samples
+ *               per pixel do not leave most lanes idle. */
+template <int M, bool PACK>
 __global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters, const uint32_t* __restrict__ order) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
-    const uint32_t slot = wave / px_per_tile; /* position in the launch order */
-    const bool wave_has_pixel = slot < rp.n_local_tiles; /* wave-uniform */
-    const uint32_t in_tile = wave - slot * px_per_tile;
-    const uint32_t local_tile = (order && wave_has_pixel) ? ldc(&order[slot]) : slot;
+    const uint32_t px_per_wave = PACK ? 64u / rp.spp : 1u;
+    const uint32_t waves_per_tile = PACK ? (px_per_tile + px_per_wave - 1) / px_per_wave : px_per_tile;
+    const uint32_t slot = wave / waves_per_tile; /* position in the launch order */
+    const bool wave_has_tile = slot < rp.n_local_tiles; /* wave-uniform */
+    const uint32_t local_tile = (order && wave_has_tile) ? ldc(&order[slot]) : slot;
 #ifdef RT_WAVE_TIMES
     const unsigned long long t_start = wall_clock64();
 #endif
+    const uint32_t sub = PACK ? lane / rp.spp : 0u;           /* pixel of the wave this lane works for */
+    const uint32_t in_tile = (wave - slot * waves_per_tile) * px_per_wave + sub;
+    const bool has_pixel = wave_has_tile && sub < px_per_wave && in_tile < px_per_tile;
     const uint32_t tile = rp.rank + local_tile * rp.world;
     const uint32_t x = rt_tile_column(tile, rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
     const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
-    const bool in_image = wave_has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
+    const bool in_image = has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
     uint32_t my_samples = 0;
-    f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane */
-    for (uint32_t s0 = 0; in_image && s0 < rp.spp; s0 += 64) {
-        const uint32_t s = s0 + lane;
+    f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane of a pixel */
+    if (in_image && rp.sample0 > 0) acc = ld3(dst);
+    if (PACK) {
+        const uint32_t first_lane = sub * rp.spp, s = rp.sample0 + (lane - first_lane);
         f3 col = mk3(0.f, 0.f, 0.f);
-        if (s < rp.spp) {
+        if (in_image) {
             Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.k = 0;
-            /* R/main.cpp:186-187 */
             float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
             primary_ray(cam, u, v, &o, &d);
-            col = trace_path<M>(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
+            col = trace_path<M>(sc, o, norm3(d), rng, cnt);
             ++my_samples;
         }
-        /* image[x + y*w] += color, one sample after the other */
-        const uint32_t n = min(64u, rp.spp - s0);
-        for (uint32_t i = 0; i < n; ++i) {
-            acc.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.x), (int)i));
-            acc.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.y), (int)i));
-            acc.z += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.z), (int)i));
+        for (uint32_t i = 0; i < rp.spp; ++i) { /* every lane of the wave takes part in the shuffles */
+            const int src = (int)(min(first_lane, 63u) + i) & 63;
+            acc.x += __shfl(col.x, src, 64);
+            acc.y += __shfl(col.y, src, 64);
+            acc.z += __shfl(col.z, src, 64);
+        }
+    } else {
+        for (uint32_t s0 = 0; in_image && s0 < rp.spp; s0 += 64) { /* in_image is wave-uniform here */
+            const uint32_t s = rp.sample0 + s0 + lane;
+            f3 col = mk3(0.f, 0.f, 0.f);
+            if (s0 + lane < rp.spp) {
+                Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.k = 0;
+                /* R/main.cpp:186-187 */
+                float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
+                float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
+                f3 o, d;
+                primary_ray(cam, u, v, &o, &d);
+                col = trace_path<M>(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
+                ++my_samples;
+            }
+            /* image[x + y*w] += color, one sample after the other */
+            const uint32_t n = min(64u, rp.spp - s0);
+            for (uint32_t i = 0; i < n; ++i) {
+                acc.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.x), (int)i));
+                acc.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.y), (int)i));
+                acc.z += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.z), (int)i));
+            }
         }
     }
-    acc = acc / (float)rp.spp; /* image /= nsamples */
-    if (wave_has_pixel && lane == 0) { dst[0] = in_image ? acc.x : 0.f; dst[1] = in_image ? acc.y : 0.f; dst[2] = in_image ? acc.z : 0.f; }
+    if (rp.sample0 + rp.spp == rp.spp_total) acc = acc / (float)rp.spp_total; /* image /= nsamples */
+    if (has_pixel && lane == (PACK ? sub * rp.spp : 0u)) { dst[0] = in_image ? acc.x : 0.f; dst[1] = in_image ? acc.y : 0.f; dst[2] = in_image ? acc.z : 0.f; }
 #ifdef RT_WAVE_TIMES
     if (lane == 0 && rt_dbg_times) {
         rt_dbg_times[3ull * wave] = t_start; rt_dbg_times[3ull * wave + 1] = wall_clock64();
@@ -185,8 +218,6 @@ __global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCa
 #endif
     flush_counters(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
 }
-
-
 RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u, float v) {
     rt_hit r;
     r.hit = h.hit ? 1 : 0;
@@ -296,6 +327,18 @@ namespace {
         }                                                                                              \
     } while (0)
 
+#define RT_RENDER_CASE(m, p, grid, stream, ...) \
+    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0>), grid, dim3(256), 0, stream, __VA_ARGS__); break;
+#define RT_DISPATCH_RENDER(mode, pack, grid, stream, ...)                                              \
+    do {                                                                                               \
+        switch (((mode) & 3) * 2 + ((pack) ? 1 : 0)) {                                                 \
+            RT_RENDER_CASE(0, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(0, 1, grid, stream, __VA_ARGS__) \
+            RT_RENDER_CASE(1, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(1, 1, grid, stream, __VA_ARGS__) \
+            RT_RENDER_CASE(2, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(2, 1, grid, stream, __VA_ARGS__) \
+            RT_RENDER_CASE(3, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(3, 1, grid, stream, __VA_ARGS__) \
+        }                                                                                              \
+    } while (0)
+
 struct SceneRes {
     rtb::Built host;
     DeviceScene dev{};
@@ -386,7 +429,7 @@ int make_render_params(uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint
     rp.n_tiles = rp.tiles_x * tiles_y;
     rp.rank = rank; rp.world = world;
     rp.n_local_tiles = (uint32_t)rt_tiles_per_rank(w, h, tile_w, tile_h, rank, world);
-    rp.pad = 0;
+    rp.sample0 = 0; rp.spp_total = spp; rp.pad[0] = rp.pad[1] = rp.pad[2] = 0;
     uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
     if (waves / 4 + 1 > 0x7fffffffull) return fail(RT_E_LIMIT, "rt_render: grid too large");
     return RT_OK;
@@ -665,19 +708,30 @@ size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_
 
 int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
                      uint32_t tile_h, uint32_t rank, uint32_t world, float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
+    return rt_render_pass_device(scene, cam, w, h, spp, 0, spp, seed, tile_w, tile_h, rank, world, d_rgb_tiles, d_counters, hip_stream);
+}
+
+int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass, uint32_t sample0,
+                          uint32_t spp_total, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
+                          float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_render: call rt_init first");
     SceneRes* r = find(scene);
     if (!r) return fail(RT_E_HANDLE, "rt_render: unknown scene");
     if (!cam || !d_rgb_tiles) return fail(RT_E_INVALID, "rt_render: null argument");
+    if ((uint64_t)sample0 + spp_pass > spp_total) return fail(RT_E_INVALID, "rt_render: pass exceeds the total sample count");
+    const uint32_t spp = spp_pass;
     RenderParams rp;
     int rc = make_render_params(w, h, spp, seed, tile_w, tile_h, rank, world, rp);
     if (rc) return rc;
+    rp.sample0 = sample0; rp.spp_total = spp_total;
     DCamera dc;
     std::string err;
     if (!rtb::invert_camera(*cam, dc, err)) return fail(RT_E_INVALID, err);
     if (rp.n_local_tiles == 0) return RT_OK;
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
-    uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
+    const bool pack = spp <= 32;
+    const uint32_t px_per_wave = pack ? 64u / spp : 1u;
+    uint64_t waves = (uint64_t)rp.n_local_tiles * (((uint64_t)tile_w * tile_h + px_per_wave - 1) / px_per_wave);
     DCamera* d_cam;
     if (g.cam_last_slot >= 0 && std::memcmp(&g.cam_last, cam, sizeof(rt_camera)) == 0) d_cam = g.cam_ring + g.cam_last_slot;
     else {
@@ -705,7 +759,7 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
         d_order = ws + rp.n_local_tiles;
     }
     dim3 grid((unsigned)((waves + 3) / 4));
-    RT_DISPATCH(r->mode, k_render, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order);
+    RT_DISPATCH_RENDER(r->mode, pack, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

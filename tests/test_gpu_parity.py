@@ -166,6 +166,44 @@ def test_tile_sharding_is_exact():
     g.close()
 
 
+def test_progressive_passes_give_the_one_shot_floats():
+    """Samples split over passes (packed-lane passes of 20 and 10, a wave-per-pixel pass of 40) continue the
+    float sum in sample order: the result is the one-shot render of 70 spp bit for bit, on a ragged image."""
+    import torch
+    o = orc.Scene.builtin(2)
+    g = api.DeviceScene(o.desc, keep=o)
+    w, h, tw, th, total = 90, 50, 16, 16, 70
+    cam = orc.camera_default(w, h)
+    ref, _ = g.render_tiles(cam, w, h, total, 11, tw, th, 0, 1)
+    dev = torch.device("cuda", 0)
+    buf = torch.full((ref.size,), 123.0, dtype=torch.float32, device=dev)  # stale contents must not matter
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    s0 = 0
+    for n in (20, 40, 10):
+        g.render_pass_device(cam, w, h, n, s0, total, 11, tw, th, 0, 1, buf.data_ptr(), 0, stream)
+        s0 += n
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(buf.cpu().numpy()), _bits(ref.ravel()))
+    with pytest.raises(api.RtError):
+        g.render_pass_device(cam, w, h, 10, 65, total, 11, tw, th, 0, 1, buf.data_ptr(), 0, stream)
+    g.close()
+
+
+def test_packed_lanes_match_the_oracle_for_every_small_spp():
+    """spp <= 32 puts 64 / spp pixels into one wave; every such grouping (including the ones that leave
+    lanes idle, and a tile whose pixel count is not a multiple of the group) matches the oracle image."""
+    o = orc.Scene.builtin(2)
+    g = api.DeviceScene(o.desc, keep=o)
+    w, h = 37, 21
+    cam = orc.camera_default(w, h)
+    for spp in (1, 2, 3, 5, 7, 8, 13, 21, 32, 33):
+        gi, gst = g.render(cam, w, h, spp, seed=spp, tile_w=5, tile_h=3)
+        oi, ost = o.render(cam, w, h, spp, orc.RT_RNG_COUNTER, spp)
+        assert gst.rays == ost.rays and gst.samples == ost.samples == w * h * spp
+        assert np.abs(gi - oi).max() <= COLOR_ATOL, spp
+    g.close()
+
+
 def test_tile_launch_order_does_not_change_the_image(tmp_path):
     """The deepest-path-first launch order of the tiles only decides when a tile is rendered: a second
     process with RTAMD_TILE_ORDER=0 (index order) produces the same floats, sharded or not."""
