@@ -139,10 +139,12 @@ typedef struct rt_stats {
     uint64_t samples;     /* primary samples traced                                         */
     uint64_t nodes;       /* shaded path nodes                                              */
     double kernel_ms;     /* device time of the render kernels (HIP events on the stream)   */
+    uint64_t bvh_nodes;   /* triangle-BVH nodes fetched (64 B each)                          */
+    uint64_t bvh_tris;    /* triangles tested inside BVH leaves (48 B each)                  */
 } rt_stats;
 
 /* Work counters on the device: RT_COUNTER_SLOTS slots of RT_COUNTER_STRIDE uint64 each
- * ({rays, samples, nodes, 0...}); a workgroup adds into slot (workgroup id % RT_COUNTER_SLOTS), so the
+ * ({rays, samples, nodes, bvh_nodes, bvh_tris, 0...}); a workgroup adds into slot (workgroup id % RT_COUNTER_SLOTS), so the
  * atomics of a launch spread over many cache lines instead of serialising on one.  The totals are
  * the sums over the slots (rt_counters_total).  The caller zeroes the buffer. */
 #define RT_COUNTER_SLOTS 1024
@@ -261,8 +263,8 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
                           uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
                           float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
 /* d_counters: NULL, or a zeroed device buffer of RT_COUNTER_WORDS uint64 (see above).  Host helper:
- * totals {rays, samples, nodes} of a counter buffer copied back to the host. */
-void rt_counters_total(const uint64_t* h_counters, uint64_t out3[3]);
+ * totals {rays, samples, nodes, bvh_nodes, bvh_tris} of a counter buffer copied back to the host. */
+void rt_counters_total(const uint64_t* h_counters, uint64_t out5[5]);
 
 /* Scatter `world` gathered tile buffers (rank-major, each padded to max_tiles_per_rank tiles)
  * into a row-major w*h*3 image.  Host helper for the gather step. */

@@ -45,19 +45,19 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 
 /* one set of atomics per workgroup, into the workgroup's slot (see RT_COUNTER_SLOTS): a single
  * shared address would serialise ~6 M atomics per frame at ~12 ns each */
+template <int M>
 RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     if (!counters) return;
-    __shared__ uint32_t part[3];
-    if (threadIdx.x < 3) part[threadIdx.x] = 0;
+    constexpr int N = (M & RT_M_BVH) ? 5 : 3; /* BVH work is only counted by the variants that traverse one */
+    __shared__ uint32_t part[5];
+    if (threadIdx.x < N) part[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t rays = wave_sum(c.rays), nodes = wave_sum(c.nodes), smp = wave_sum(samples);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&part[0], rays);
-        atomicAdd(&part[1], smp);
-        atomicAdd(&part[2], nodes);
-    }
+    uint32_t v[5] = {wave_sum(c.rays), wave_sum(samples), wave_sum(c.nodes), 0u, 0u};
+    if (N == 5) { v[3] = wave_sum(c.bvh_nodes); v[4] = wave_sum(c.bvh_tris); }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < N; ++k) atomicAdd(&part[k], v[k]);
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < N) {
         uint64_t* slot = counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_STRIDE;
         atomicAdd((unsigned long long*)&slot[threadIdx.x], (unsigned long long)part[threadIdx.x]);
     }
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
         float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
         f3 o, d;
         primary_ray(cam, u, v, &o, &d);
-        Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
+        Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
         Rng rng; rng.key = 0; rng.k = 0;
         (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
         deepest = max(deepest, cnt.nodes);
@@ -141,7 +141,7 @@ extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
  * PACK = true : spp <= 32, 64 / spp pixels per wave, lane = (pixel, sample), so that few samples
  *               per pixel do not leave most lanes idle. */
 template <int M, bool PACK>
-__global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
+__global__ __launch_bounds__(256, 4) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters, const uint32_t* __restrict__ order) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCa
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
     const bool in_image = has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
     uint32_t my_samples = 0;
     f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane of a pixel */
     if (in_image && rp.sample0 > 0) acc = ld3(dst);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) RT_OCC void k_render(DeviceScene sc, const DCa
         rt_dbg_times[3ull * wave + 2] = ((unsigned long long)y << 32) | x;
     }
 #endif
-    flush_counters(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
+    flush_counters<M>(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
 }
 RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u, float v) {
     rt_hit r;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* 
     if (i >= n) return;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
     HitRec rec = closest_rec<M>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
     int tri = (h.hit && h.type == RT_MESH) ? (int)ldc(&sc.tri_orig[h.tri]) : -1;
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     const DMesh m = ldc(&sc.meshes[mesh]);
-    if (mesh_closest<RT_M_BVH>(sc, m, o, d, s_stack + threadIdx.x, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
+    if (mesh_closest<RT_M_BVH>(sc, m, o, d, cnt, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
     FullHit h = finish_hit(sc, rec, o, d);
     out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)ldc(&sc.tri_orig[h.tri]) : -1, rec.u, rec.v);
 }
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __re
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.stack = s_stack + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
     uint32_t smp = 0;
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __re
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
         smp = 1;
     }
-    flush_counters(counters, cnt, smp);
+    flush_counters<M>(counters, cnt, smp);
 }
 
 __global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __restrict__ u, const float* __restrict__ v, size_t n,
@@ -673,7 +674,7 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
     std::vector<uint64_t> slots(RT_COUNTER_WORDS);
-    uint64_t cnt[3];
+    uint64_t cnt[5];
     HIP_TRY(hipMemcpyAsync(rgb, d_c, 12 * n, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -682,6 +683,7 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
+        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4];
     }
     return RT_OK;
 }
@@ -694,10 +696,10 @@ void rt_normalize_dirs(const float* dir, size_t n, float* out) {
     }
 }
 
-void rt_counters_total(const uint64_t* h, uint64_t out3[3]) {
-    out3[0] = out3[1] = out3[2] = 0;
+void rt_counters_total(const uint64_t* h, uint64_t out5[5]) {
+    for (int k = 0; k < 5; ++k) out5[k] = 0;
     for (size_t s = 0; s < RT_COUNTER_SLOTS; ++s)
-        for (int k = 0; k < 3; ++k) out3[k] += h[s * RT_COUNTER_STRIDE + k];
+        for (int k = 0; k < 5; ++k) out5[k] += h[s * RT_COUNTER_STRIDE + k];
 }
 
 size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world) {
@@ -781,7 +783,7 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
     if ((rc = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, rank, world, (float*)d_out, (uint64_t*)d_cnt, g.stream))) return rc;
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
     std::vector<uint64_t> slots(RT_COUNTER_WORDS);
-    uint64_t cnt[3];
+    uint64_t cnt[5];
     if (bytes) HIP_TRY(hipMemcpyAsync(rgb_tiles, d_out, bytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -790,6 +792,7 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
+        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4];
     }
     return RT_OK;
 }

@@ -122,8 +122,9 @@ void edge_interval(float len, float& lo, float& hi) {
 
 /* ---- triangle BVH (per mesh) ---------------------------------------------------------------
  * Binned surface-area-heuristic build over the scaled triangles the device tests (v0, v0+e1, v0+e2).
- * Leaves hold at most 4 triangles; if the SAH recursion gets deeper than kBvhMaxDepth it switches
- * to median splits, which bounds the depth (and the device's traversal stack).  Leaf triangles are
+ * Leaves hold at most 4 triangles.  A node at depth D with c triangles splits by SAH only while
+ * D + 1 + ceil(log2 c) <= kBvhMaxDepth + 2, otherwise at the median: median splits below any node
+ * then end within kBvhMaxDepth inner levels, which is the size of the device's traversal stack.  Leaf triangles are
  * written back in leaf order, with their original indices kept in tri_orig. */
 struct BBox {
     float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
@@ -141,6 +142,7 @@ struct BvhBuilder {
     std::vector<DBvhNode>& nodes;
     std::vector<uint32_t> order; /* triangle ids in leaf order */
     float pad;
+    int max_depth = 0; /* inner nodes on the longest path */
     BvhBuilder(std::vector<TriInfo>& p, std::vector<DBvhNode>& n, float pad_) : prims(p), nodes(n), pad(pad_) {}
 
     struct Child { bool leaf; int32_t index; int32_t count; BBox box; };
@@ -155,7 +157,10 @@ struct BvhBuilder {
         if (ext[2] > ext[axis]) axis = 2;
         uint32_t mid = first + count / 2;
         bool split_ok = false;
-        if (depth < kBvhMaxDepth - 24 && ext[axis] > 0.f) { /* binned SAH */
+        int log2c = 0;
+        while ((1ull << log2c) < count) ++log2c;
+        max_depth = std::max(max_depth, depth + 1);
+        if (depth + 1 + log2c <= kBvhMaxDepth + 2 && ext[axis] > 0.f) { /* binned SAH */
             const int B = 16;
             BBox bb[B]; uint32_t bn[B] = {0};
             float k = B * (1.f - 1e-6f) / ext[axis];
@@ -205,7 +210,7 @@ struct BvhBuilder {
 
 /* Builds the BVH of the triangles [first, first+count) of out.tris, reorders them into leaf order
  * and returns the root node index (a mesh with one leaf still gets a root node). */
-int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count) {
+int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count, DMesh& mesh) {
     std::vector<TriInfo> prims(count);
     BBox all;
     for (uint32_t i = 0; i < count; ++i) {
@@ -225,6 +230,17 @@ int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count) {
     BvhBuilder b(prims, out.bvh, pad);
     BvhBuilder::Child top = b.build(0, count, 0);
     if (top.leaf) return -1; /* cannot happen for count > 4; the caller then keeps the brute-force loop */
+    if (b.max_depth > kBvhMaxDepth) return -2; /* cannot happen either (see the split rule) */
+    for (int a = 0; a < 3; ++a) { mesh.lo[a] = all.lo[a] - pad; mesh.hi[a] = all.hi[a] + pad; }
+    { /* bounding sphere of the padded box, in double, every rounding outward */
+        double c[3], r2 = 0.0;
+        for (int a = 0; a < 3; ++a) { mesh.bs_c[a] = (float)(0.5 * ((double)all.lo[a] + (double)all.hi[a])); c[a] = mesh.bs_c[a]; }
+        for (int a = 0; a < 3; ++a) {
+            double e = std::max(std::fabs((double)all.lo[a] - pad - c[a]), std::fabs((double)all.hi[a] + pad - c[a]));
+            r2 += e * e;
+        }
+        mesh.bs_r2 = std::nextafter((float)(r2 * 1.0001), kInf);
+    }
     /* leaf indices are relative to this mesh: make them global, and permute the triangles */
     std::vector<DTri> sorted(count);
     for (uint32_t i = 0; i < count; ++i) { sorted[i] = out.tris[first + b.order[i]]; out.tri_orig[first + i] = b.order[i]; }
@@ -298,7 +314,10 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
             out.tris.push_back(tr);
             out.tri_orig.push_back(t);
         }
-        if (m.n_triangles > kBvhMinTris) o.bvh_root = build_mesh_bvh(out, o.first_tri, o.n_tris);
+        if (m.n_triangles > kBvhMinTris) {
+            o.bvh_root = build_mesh_bvh(out, o.first_tri, o.n_tris, o);
+            if (o.bvh_root < -1) return fail(err, "rt_scene_create: triangle BVH deeper than the traversal stack");
+        }
         out.meshes.push_back(o);
     }
     out.normals.assign(d.normals, d.normals + 3 * (size_t)d.n_vertices);

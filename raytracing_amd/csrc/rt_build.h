@@ -28,7 +28,7 @@ struct Built {
 
 /* meshes with more than kBvhMinTris triangles get a BVH; smaller ones keep the reference's loop */
 const uint32_t kBvhMinTris = 64;
-const int kBvhMaxDepth = 60;
+const int kBvhMaxDepth = 32; /* inner nodes on any root-to-leaf path = entries of the device's traversal stack */
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err);
 bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err);
 

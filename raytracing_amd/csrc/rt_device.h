@@ -100,13 +100,12 @@ RT_DEV T ldc(const T* p) {
 
 /* per-lane context: work counters (summed per workgroup at the end) and the base of this lane's
  * slice of the LDS traversal stack (element i lives at stack[i * RT_STACK_STRIDE]) */
-struct Cnt { uint32_t rays, nodes; uint32_t* stack; };
+struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris; /* BVH nodes fetched, triangles tested */ };
 /* kernel variants: bit 0 = the object kd-tree has internal nodes, bit 1 = some mesh has a triangle BVH.
  * Code a scene cannot reach is compiled out of its variant, which keeps the common variant's registers low. */
 #define RT_M_KD 1
 #define RT_M_BVH 2
-#define RT_STACK_LDS 16      /* entries per lane kept in LDS */
-#define RT_STACK_SPILL 48    /* deeper entries go to a per-lane private array */
+#define RT_STACK_LDS 32      /* entries per lane, all in LDS: the host bounds the BVH depth to this (kBvhMaxDepth) */
 #define RT_STACK_STRIDE 256  /* workgroup size: lane-interleaved, conflict-free LDS layout */
 
 /* closest hit so far: enough to rebuild position and normal of the winner afterwards */
@@ -218,8 +217,10 @@ RT_DEV bool tri_t(const DTri& tr, f3 o, f3 d, float& t, float& u, float& v) {
  * The boxes only decide which triangles get tested; they are padded on the host and a subtree is
  * skipped only when its box is missed or starts beyond the best t so far.
  * while-while form: descend through inner nodes until a leaf entry is reached, then test the
- * leaf's triangles; one 64-byte node holds both child boxes.  The stack keeps its first
- * RT_STACK_LDS entries in LDS (lane-interleaved) and spills deeper ones to private memory.
+ * leaf's triangles; one 64-byte node holds both child boxes.  The stack lives in LDS, lane-interleaved;
+ * the host bounds the tree depth to its RT_STACK_LDS entries.
+ * The box tests only steer the traversal, so they use v_rcp_f32 (1 ulp) instead of IEEE divisions: the
+ * boxes are padded by 1e-4 of the mesh diagonal, four orders of magnitude more than that error.
  * Stack entries: >= 0 inner node index; < 0 leaf, ~entry = first_triangle * 8 + count (count <= 4). */
 RT_DEV bool slab(const float lo[3], const float hi[3], f3 o, f3 id, float limit, float& tn) {
     float x1 = (lo[0] - o.x) * id.x, x2 = (hi[0] - o.x) * id.x;
@@ -232,28 +233,32 @@ RT_DEV bool slab(const float lo[3], const float hi[3], f3 o, f3 id, float limit,
     return tn <= tf;
 }
 template <bool ANY>
-RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, uint32_t* stack, float& best_t, int& best_tri,
+RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
                          float& best_u, float& best_v) {
-    const f3 id = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t spill[RT_STACK_SPILL];
+    best_t = ANY ? dist : 3.402823466e+38f; /* FLT_MAX, the reference's initial closest t */
+    { /* Division-free early out against the mesh's bounding sphere (most rays of a scene never come
+       * near a given mesh).  b and c2 carry a rounding error of a few 2^-24 * c2, d is unit to 2^-23:
+       * the 1e-6 * c2 slack keeps every rejection certain.  NaN / inf operands reject nothing. */
+        const f3 oc = ld3(m.bs_c) - o;
+        const float b = dot3(oc, d), c2 = dot3(oc, oc);
+        const float r2 = m.bs_r2 + 1e-6f * c2;
+        if (c2 - b * b > r2) return false;   /* the line misses the sphere */
+        if (b < 0.f && c2 > r2) return false; /* the sphere lies behind the origin */
+        if (ANY && b > dist) { const float e = b - dist; if (e * e > r2) return false; } /* ... or beyond the light */
+    }
+    const f3 id = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    { float tn; if (!slab(m.lo, m.hi, o, id, best_t, tn)) return false; }
     int sp = 0;
     bool found = false;
-    best_t = ANY ? dist : 3.402823466e+38f; /* FLT_MAX, the reference's initial closest t */
     uint32_t best_orig = 0xffffffffu;
     int cur = m.bvh_root;
-    auto push = [&](int e) {
-        if (sp < RT_STACK_LDS) stack[sp * RT_STACK_STRIDE] = (uint32_t)e;
-        else if (sp < RT_STACK_LDS + RT_STACK_SPILL) spill[sp - RT_STACK_LDS] = (uint32_t)e;
-        ++sp; /* the host bounds the tree depth, so the stack cannot overflow */
-    };
-    auto pop = [&]() -> int {
-        --sp;
-        return (int)(sp < RT_STACK_LDS ? stack[sp * RT_STACK_STRIDE] : spill[sp - RT_STACK_LDS]);
-    };
+    auto push = [&](int e) { cnt.stack[(sp++ & (RT_STACK_LDS - 1)) * RT_STACK_STRIDE] = (uint32_t)e; }; /* never wraps: depth <= RT_STACK_LDS */
+    auto pop = [&]() -> int { return (int)cnt.stack[(--sp & (RT_STACK_LDS - 1)) * RT_STACK_STRIDE]; };
     for (;;) {
         bool done = false;
         while (cur >= 0) { /* inner nodes */
             const DBvhNode n = ldc(&sc.bvh[cur]);
+            ++cnt.bvh_nodes;
             float t0, t1;
             bool h0 = slab(n.lo0, n.hi0, o, id, best_t, t0) && !(n.n0 == 0 && n.c0 < 0);
             bool h1 = slab(n.lo1, n.hi1, o, id, best_t, t1) && !(n.n1 == 0 && n.c1 < 0);
@@ -272,6 +277,7 @@ RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
         { /* leaf */
             int code = ~cur;
             int first = code >> 3, count = code & 7;
+            cnt.bvh_tris += (uint32_t)count;
             for (int k = 0; k < count; ++k) {
                 float t, u, v;
                 if (tri_t(ldc(&sc.tris[first + k]), o, d, t, u, v) && t > 1e-6f) {
@@ -293,8 +299,8 @@ RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
 
 /* ---- Mesh::intersect closest loop, R/src/Mesh.h:225-277 (brute force over the slice) ----- */
 template <int M>
-RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, uint32_t* stack, float& best_t, int& best_tri, float& best_u, float& best_v) {
-    if ((M & RT_M_BVH) && m.bvh_root >= 0) return bvh_traverse<false>(sc, m, o, d, 0.f, stack, best_t, best_tri, best_u, best_v);
+RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, Cnt& cnt, float& best_t, int& best_tri, float& best_u, float& best_v) {
+    if ((M & RT_M_BVH) && m.bvh_root >= 0) return bvh_traverse<false>(sc, m, o, d, 0.f, cnt, best_t, best_tri, best_u, best_v);
     bool found = false;
     best_t = 3.402823466e+38f; /* FLT_MAX */
     for (uint32_t i = 0; i < m.n_tris; ++i) {
@@ -306,11 +312,11 @@ RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, uint
     return found;
 }
 template <int M>
-RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, uint32_t* stack) {
+RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt) {
     if ((M & RT_M_BVH) && m.bvh_root >= 0) {
         float t, u, v;
         int tri;
-        return bvh_traverse<true>(sc, m, o, d, dist, stack, t, tri, u, v);
+        return bvh_traverse<true>(sc, m, o, d, dist, cnt, t, tri, u, v);
     }
     for (uint32_t i = 0; i < m.n_tris; ++i) {
         float t, u, v;
@@ -321,7 +327,7 @@ RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
 
 /* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------ */
 template <int M>
-RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, uint32_t* stack, HitRec& best) {
+RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, Cnt& cnt, HitRec& best) {
     bool any = false;
     for (int r = first; r < first + count; ++r) {
         DRef ref = ldc(&sc.refs[r]);
@@ -330,7 +336,7 @@ RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d
         bool ok;
         if (ref.type == RT_SPHERE) ok = sphere_t(ldc(&sc.spheres[ref.object]), o, d, t);
         else if (ref.type == RT_SQUARE) ok = square_t(ldc(&sc.squares[ref.object]), o, d, t);
-        else ok = mesh_closest<M>(sc, ldc(&sc.meshes[ref.object]), o, d, stack, t, tri, u, v);
+        else ok = mesh_closest<M>(sc, ldc(&sc.meshes[ref.object]), o, d, cnt, t, tri, u, v);
         if (ok) {
             any = true;
             if (best.type < 0 || t < best.t) { best.t = t; best.type = ref.type; best.obj = ref.object; best.tri = tri; best.u = u; best.v = v; }
@@ -360,7 +366,7 @@ RT_DEV void for_each_record(const Rec* tab, uint32_t n, F&& f) {
     }
 }
 template <int M>
-RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, uint32_t* stack, HitRec& best) {
+RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt, HitRec& best) {
     for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& rec, uint32_t i) {
         float t;
         if (sphere_t(rec, o, d, t) && (best.type < 0 || t < best.t)) { best.t = t; best.type = RT_SPHERE; best.obj = (int)i; }
@@ -372,20 +378,20 @@ RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, uint32_t* stack, Hit
     for (uint32_t i = 0; i < sc.n_meshes; ++i) {
         float t, u, v;
         int tri;
-        if (mesh_closest<M>(sc, ldc(&sc.meshes[i]), o, d, stack, t, tri, u, v) && (best.type < 0 || t < best.t)) {
+        if (mesh_closest<M>(sc, ldc(&sc.meshes[i]), o, d, cnt, t, tri, u, v) && (best.type < 0 || t < best.t)) {
             best.t = t; best.type = RT_MESH; best.obj = (int)i; best.tri = tri; best.u = u; best.v = v;
         }
     }
 }
 /* shadow query on a leaf: "closest hit exists and its t < dist" == "some object reports t < dist" */
 template <int M>
-RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist, uint32_t* stack) {
+RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, float dist, Cnt& cnt) {
     for (int r = first; r < first + count; ++r) {
         DRef ref = ldc(&sc.refs[r]);
         float t;
         if (ref.type == RT_SPHERE) { if (sphere_t(ldc(&sc.spheres[ref.object]), o, d, t) && t < dist) return true; }
         else if (ref.type == RT_SQUARE) { if (square_t(ldc(&sc.squares[ref.object]), o, d, t) && t < dist) return true; }
-        else { if (mesh_any<M>(sc, ldc(&sc.meshes[ref.object]), o, d, dist, stack)) return true; }
+        else { if (mesh_any<M>(sc, ldc(&sc.meshes[ref.object]), o, d, dist, cnt)) return true; }
     }
     return false;
 }
@@ -396,7 +402,7 @@ RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, fl
  * uses it to decide whether the far child is visited. */
 #define RT_KD_MAX_DEPTH 16
 template <int M>
-RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_out, uint32_t* stack, HitRec& best) {
+RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_out, Cnt& cnt, HitRec& best) {
     /* frame = far child id * 4 + state, plane distance, exit distance of the level.
      * state 0: near subtree running; 1 / 2: far subtree running after near returned false / true */
     int f_node[RT_KD_MAX_DEPTH];
@@ -406,7 +412,7 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
     for (;;) {
         for (;;) { /* descend until a leaf */
             DKdNode nd = ldc(&sc.kd[node]);
-            if (nd.leaf) { ret = leaf_closest<M>(sc, nd.first_ref, nd.n_refs, o, d, stack, best); break; }
+            if (nd.leaf) { ret = leaf_closest<M>(sc, nd.first_ref, nd.n_refs, o, d, cnt, best); break; }
             float da = comp(d, nd.axis), oa = comp(o, nd.axis);
             float t_split = (__builtin_fabsf(da) < sc.kd_epsilon) ? RT_INF : (nd.cut - oa) / da;
             int near_id = (da >= 0.f) ? nd.left : nd.right;
@@ -451,10 +457,10 @@ RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
     if (sc.n_kd == 0) return best;
     if (!(M & RT_M_KD)) { /* the root is a leaf (every built-in scene): only pass / fail of the box matters */
         if (!inside_box(sc.box_lo, sc.box_hi, o) && !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-        root_closest<M>(sc, o, d, cnt.stack, best);
+        root_closest<M>(sc, o, d, cnt, best);
     } else {
         if (!box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return best;
-        kd_closest<M>(sc, o, d, t_in, t_out, cnt.stack, best);
+        kd_closest<M>(sc, o, d, t_in, t_out, cnt, best);
     }
     return best;
 }
@@ -482,10 +488,10 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
     ++cnt.rays;
     float t_in, t_out;
     if (sc.n_kd == 0 || !box_test(sc.box_lo, sc.box_hi, o, d, t_in, t_out)) return false;
-    if (!(M & RT_M_KD)) return leaf_any<M>(sc, 0, (int)sc.n_refs, o, d, dist, cnt.stack);
+    if (!(M & RT_M_KD)) return leaf_any<M>(sc, 0, (int)sc.n_refs, o, d, dist, cnt);
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
-    return kd_closest<M>(sc, o, d, t_in, t_out, cnt.stack, best) && best.type >= 0 && best.t < dist;
+    return kd_closest<M>(sc, o, d, t_in, t_out, cnt, best) && best.type >= 0 && best.t < dist;
 }
 
 /* Shadow queries of one shaded point, RT_SB at a time (root-leaf scenes).  All rays of a batch leave the
@@ -547,7 +553,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
         if ((M & RT_M_BVH) && m.bvh_root >= 0) { /* large mesh: one BVH traversal per ray */
 #pragma unroll
             for (int j = 0; j < RT_SB; ++j)
-                if (!occ[j] && act[j] && mesh_any<M>(sc, m, o, d[j], dist[j], cnt.stack)) occ[j] = true;
+                if (!occ[j] && act[j] && mesh_any<M>(sc, m, o, d[j], dist[j], cnt)) occ[j] = true;
             continue;
         }
         for_each_record(sc.tris + m.first_tri, m.n_tris, [&](const DTri& tr, uint32_t) {

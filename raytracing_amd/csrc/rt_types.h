@@ -56,11 +56,14 @@ struct DTri {  /* 48 B: one Moller-Trumbore test reads exactly this */
     float e2[3]; uint32_t i2;
 };
 
-struct DMesh {  /* 32 B */
+struct DMesh {  /* 64 B */
     uint32_t first_tri, n_tris;
     int32_t mat;
     int32_t bvh_root;  /* index into DeviceScene::bvh, -1 = brute force over the triangle range */
-    int32_t pad[4];
+    float bs_c[3];     /* with a BVH: a sphere around the padded root box; a ray whose line misses it, or */
+    float bs_r2;       /* that leaves it behind, skips the traversal (squared radius, rounded up)         */
+    float lo[3]; float pad0; /* the padded root box itself */
+    float hi[3]; float pad1;
 };
 
 /* Triangle BVH node (binary, 64 B = one cache-line half, four dwordx4 loads): the boxes of BOTH

@@ -30,5 +30,8 @@ g = hs.upload()
 cam = host.camera_default(a.width, a.height)
 for i in range(a.steps):
     _, st = g.render_tiles(cam, a.width, a.height, a.spp, seed=1)
-    print(f"step {i}: {st.rays} rays ({st.rays / st.samples:.2f}/sample), kernel {st.kernel_ms:.3f} ms, {st.rays / st.kernel_ms / 1e3:.1f} Mrays/s", flush=True)
+    bytes_per_ray = (st.bvh_nodes * 64 + st.bvh_tris * 48) / st.rays + 32 + 12 * st.samples / st.rays
+    print(f"step {i}: {st.rays} rays ({st.rays / st.samples:.2f}/sample), kernel {st.kernel_ms:.3f} ms, {st.rays / st.kernel_ms / 1e3:.1f} Mrays/s; "
+          f"BVH nodes/ray {st.bvh_nodes / st.rays:.2f}, triangles/ray {st.bvh_tris / st.rays:.2f}, algorithmic {bytes_per_ray:.0f} B/ray "
+          f"= {bytes_per_ray * st.rays / st.kernel_ms / 1e9:.2f} TB/s", flush=True)
 g.close()
