@@ -539,13 +539,25 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
             occ[j] = occ[j] || (t < dist[j]);
         }
     });
+    /* Squares: the plane distance decides "0 <= t < dist" long before its last bit matters.  num * rcp(den)
+     * is within 1.5 * 2^-23 of the exact quotient (v_rcp_f32: 1 ulp, one rounding of the product), so a
+     * value below -1e-30 means the correctly rounded t is negative, and a value above dist * (1 + 2^-20)
+     * means it is >= dist: both are misses whatever the rectangle test would say.  Everything else
+     * (including NaN, zero and denormal results) takes the reference's division. */
+    float dist_hi[RT_SB];
+#pragma unroll
+    for (int j = 0; j < RT_SB; ++j) dist_hi[j] = dist[j] * 1.000001f;
     for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t) {
         f3 v0 = ld3(q.v0), n = ld3(q.n);
         float num = dot3(v0 - o, n);
 #pragma unroll
         for (int j = 0; j < RT_SB; ++j) {
-            float tt = num / dot3(d[j], n);
-            if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
+            float den = dot3(d[j], n);
+            float ta = num * __builtin_amdgcn_rcpf(den);
+            if (!(ta < -1e-30f) && !(ta > dist_hi[j])) {
+                float tt = num / den;
+                if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
+            }
         }
     });
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {

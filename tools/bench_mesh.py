@@ -23,10 +23,14 @@ off = os.path.join(tempfile.gettempdir(), f"grid_{a.n}.off")
 if not os.path.exists(off):
     p, t = make_mesh_off.make(a.n)
     make_mesh_off.write_off(off, p, t)
+import time  # noqa: E402
 api.init(0)
+t0 = time.perf_counter()
 hs = host.HostScene.mesh_file(off, with_spheres=a.spheres)
-print(f"mesh: {hs.desc.n_triangles} triangles, {hs.desc.n_vertices} vertices", flush=True)
+t1 = time.perf_counter()
+print(f"mesh: {hs.desc.n_triangles} triangles, {hs.desc.n_vertices} vertices; loadOFF + normals + flatten {t1 - t0:.2f} s", flush=True)
 g = hs.upload()
+print(f"rt_scene_create (host BVH build + upload) {time.perf_counter() - t1:.2f} s", flush=True)
 cam = host.camera_default(a.width, a.height)
 for i in range(a.steps):
     _, st = g.render_tiles(cam, a.width, a.height, a.spp, seed=1)
