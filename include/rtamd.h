@@ -196,6 +196,18 @@ int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches);
 int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out);
 int rt_scene_destroy(rt_scene_t scene);
 
+/* Host-only dry run of rt_scene_create (needs neither rt_init nor a GPU): validates the description, builds
+ * the object kd-tree and the triangle BVHs, checks the BVHs (every triangle in exactly one leaf, boxes nested
+ * and enclosing their triangles, depth within the device's traversal stack) and reports what was built. */
+typedef struct rt_build_info {
+    uint32_t kd_nodes, kd_max_depth;  /* object kd-tree (R/src/KDTree.cpp:363-519) */
+    uint32_t bvh_meshes, bvh_nodes;   /* meshes that got a triangle BVH, total 64-byte nodes */
+    uint32_t bvh_max_depth;           /* inner nodes on the longest root-to-leaf path (limit 32) */
+    uint32_t kernel_variant;          /* bit 0: kd-tree has internal nodes, bit 1: some mesh has a BVH */
+    uint64_t device_bytes;            /* size of the scene tables in HBM */
+} rt_build_info;
+int rt_scene_check(const rt_scene_desc* desc, rt_build_info* info);
+
 /* Flattened object kd-tree, for inspection / parity tests.  nodes: 8 int32 per node
  * {is_leaf, axis, cut(float bits), left, right, first_ref, n_refs, depth}; refs: 2 int32 per
  * reference {type, object}; root_box: min xyz, max xyz.  Pass NULL buffers to query counts. */

@@ -63,12 +63,17 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64)]
 
 
+class BuildInfo(C.Structure):
+    _fields_ = [("kd_nodes", C.c_uint32), ("kd_max_depth", C.c_uint32), ("bvh_meshes", C.c_uint32), ("bvh_nodes", C.c_uint32),
+                ("bvh_max_depth", C.c_uint32), ("kernel_variant", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri", "<i4"), ("t", "<f4"),
                       ("u", "<f4"), ("v", "<f4"), ("pad0", "<f4"), ("p", "<f4", 3), ("pad1", "<f4"),
                       ("n", "<f4", 3), ("pad2", "<f4")])
 
 # every symbol include/rtamd.h declares
-EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_kdtree",
+EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
            "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_tiles_to_image", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
@@ -86,6 +91,7 @@ def lib():
         vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
         L.rt_last_error.restype = C.c_char_p
         L.rt_init.argtypes = [C.c_int]
+        L.rt_scene_check.argtypes = [C.POINTER(SceneDesc), C.POINTER(BuildInfo)]
         L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(u64)]
         L.rt_scene_destroy.argtypes = [u64]
         L.rt_scene_kdtree.argtypes = [u64, vp, C.POINTER(u32), vp, C.POINTER(u32), vp]
@@ -218,6 +224,13 @@ class DeviceScene:
         cam = cam if isinstance(cam, Camera) else copy_struct(Camera, cam)
         check(lib().rt_render_pass_device(self.h, C.byref(cam), w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank,
                                           world, C.c_void_p(d_out_ptr), C.c_void_p(d_counters_ptr), C.c_void_p(stream_ptr)))
+
+
+def scene_check(desc):
+    """Host-only dry run of rt_scene_create (no GPU): builds and verifies kd-tree and BVHs, returns BuildInfo."""
+    info = BuildInfo()
+    check(lib().rt_scene_check(C.byref(desc), C.byref(info)))
+    return info
 
 
 def normalize_dirs(dirs):

@@ -504,6 +504,27 @@ int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches) {
     return RT_OK;
 }
 
+int rt_scene_check(const rt_scene_desc* desc, rt_build_info* info) {
+    if (!desc || !info) return fail(RT_E_INVALID, "rt_scene_check: null argument");
+    std::memset(info, 0, sizeof(*info));
+    rtb::Built b;
+    std::string err;
+    if (!rtb::build_scene(*desc, b, err)) return fail(RT_E_INVALID, err);
+    int kd_depth = 0, bvh_depth = 0;
+    for (const DKdNode& k : b.kd) kd_depth = k.depth > kd_depth ? k.depth : kd_depth;
+    if (kd_depth >= RT_KD_MAX_DEPTH) return fail(RT_E_LIMIT, "rt_scene_check: kd-tree deeper than 15 levels");
+    if (!rtb::verify_bvh(b, bvh_depth, err)) return fail(RT_E_LIMIT, err);
+    info->kd_nodes = (uint32_t)b.kd.size(); info->kd_max_depth = (uint32_t)kd_depth;
+    for (const DMesh& m : b.meshes) info->bvh_meshes += m.bvh_root >= 0 ? 1u : 0u;
+    info->bvh_nodes = (uint32_t)b.bvh.size(); info->bvh_max_depth = (uint32_t)bvh_depth;
+    info->kernel_variant = ((!b.kd.empty() && b.kd[0].leaf) ? 0u : (uint32_t)RT_M_KD) | (b.bvh.empty() ? 0u : (uint32_t)RT_M_BVH);
+    info->device_bytes = b.spheres.size() * sizeof(DSphere) + b.squares.size() * sizeof(DSquare) + b.meshes.size() * sizeof(DMesh) +
+                         b.tris.size() * sizeof(DTri) + b.tri_orig.size() * 4 + b.bvh.size() * sizeof(DBvhNode) + b.normals.size() * 4 +
+                         b.materials.size() * sizeof(DMaterial) + b.lights.size() * sizeof(DLight) + b.kd.size() * sizeof(DKdNode) +
+                         b.refs.size() * sizeof(DRef);
+    return RT_OK;
+}
+
 int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_scene_create: call rt_init first");
     if (!desc || !out) return fail(RT_E_INVALID, "rt_scene_create: null argument");

@@ -255,6 +255,59 @@ int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count, DMesh& mesh) 
 
 }  // namespace
 
+bool verify_bvh(const Built& b, int& max_depth, std::string& err) {
+    max_depth = 0;
+    std::vector<uint8_t> seen(b.tris.size(), 0);
+    struct Item { int32_t node; int depth; float lo[3], hi[3]; };
+    for (size_t mi = 0; mi < b.meshes.size(); ++mi) {
+        const DMesh& m = b.meshes[mi];
+        if (m.bvh_root < 0) continue;
+        std::vector<Item> todo;
+        Item root{m.bvh_root, 1, {m.lo[0], m.lo[1], m.lo[2]}, {m.hi[0], m.hi[1], m.hi[2]}};
+        todo.push_back(root);
+        size_t leaves_tris = 0;
+        while (!todo.empty()) {
+            Item it = todo.back(); todo.pop_back();
+            if (it.node < 0 || (size_t)it.node >= b.bvh.size()) return fail(err, "bvh: node index out of range");
+            if (it.depth > kBvhMaxDepth) return fail(err, "bvh: path longer than the traversal stack");
+            max_depth = std::max(max_depth, it.depth);
+            const DBvhNode& n = b.bvh[(size_t)it.node];
+            const float* lo[2] = {n.lo0, n.lo1}; const float* hi[2] = {n.hi0, n.hi1};
+            const int32_t c[2] = {n.c0, n.c1}, cnt[2] = {n.n0, n.n1};
+            for (int k = 0; k < 2; ++k) {
+                if (cnt[k] == 0 && c[k] < 0) continue; /* empty child */
+                for (int a = 0; a < 3; ++a)
+                    if (lo[k][a] < it.lo[a] || hi[k][a] > it.hi[a]) return fail(err, "bvh: child box sticks out of its parent");
+                if (cnt[k] == 0) {
+                    Item ch{c[k], it.depth + 1, {lo[k][0], lo[k][1], lo[k][2]}, {hi[k][0], hi[k][1], hi[k][2]}};
+                    todo.push_back(ch);
+                    continue;
+                }
+                if (cnt[k] < 1 || cnt[k] > 4) return fail(err, "bvh: leaf size outside 1..4");
+                for (int32_t t = c[k]; t < c[k] + cnt[k]; ++t) {
+                    if (t < (int32_t)m.first_tri || t >= (int32_t)(m.first_tri + m.n_tris)) return fail(err, "bvh: leaf triangle outside the mesh");
+                    if (seen[(size_t)t]++) return fail(err, "bvh: triangle in two leaves");
+                    ++leaves_tris;
+                    const DTri& tr = b.tris[(size_t)t];
+                    for (int a = 0; a < 3; ++a) {
+                        float v[3] = {tr.v0[a], tr.v0[a] + tr.e1[a], tr.v0[a] + tr.e2[a]};
+                        for (float x : v)
+                            if (x < lo[k][a] || x > hi[k][a]) return fail(err, "bvh: triangle vertex outside its leaf box");
+                    }
+                }
+            }
+        }
+        if (leaves_tris != m.n_tris) return fail(err, "bvh: a triangle is in no leaf");
+        /* tri_orig is a permutation of the mesh-local indices */
+        std::vector<uint8_t> hit(m.n_tris, 0);
+        for (uint32_t t = 0; t < m.n_tris; ++t) {
+            uint32_t o = b.tri_orig[m.first_tri + t];
+            if (o >= m.n_tris || hit[o]++) return fail(err, "bvh: tri_orig is not a permutation");
+        }
+    }
+    return true;
+}
+
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
     out = Built();
     if ((d.n_spheres && !d.spheres) || (d.n_squares && !d.squares) || (d.n_meshes && !d.meshes) ||

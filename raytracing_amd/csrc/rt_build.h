@@ -30,6 +30,10 @@ struct Built {
 const uint32_t kBvhMinTris = 64;
 const int kBvhMaxDepth = 32; /* inner nodes on any root-to-leaf path = entries of the device's traversal stack */
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err);
+/* Walks every triangle BVH of a built scene: each triangle of a BVH mesh sits in exactly one leaf, leaves hold
+ * 1..4 triangles, every child box contains the (padded) boxes below it and its triangles' vertices, and no
+ * root-to-leaf path has more than kBvhMaxDepth inner nodes.  max_depth returns the longest path found. */
+bool verify_bvh(const Built& b, int& max_depth, std::string& err);
 bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err);
 
 }  // namespace rtb
