@@ -44,6 +44,13 @@ def cpu_baseline(w, h, spp, seed, threads=1):
     rec = {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"same scene and camera, {w}x{h} at {spp} spp ({st.samples} samples, {st.rays} rays, {dt:.1f} s)",
            "rays_per_sample": round(st.rays / st.samples, 3)}
+    # the reference is single-threaded; the counter RNG also allows row-parallel workers: the same sample on 16 cores
+    many = min(16, os.cpu_count() or 1)
+    if many > 1:
+        t0 = time.perf_counter()
+        _, st2 = scene.render(cam, w, h, spp, orc.RT_RNG_COUNTER, seed, threads=many)
+        dt2 = time.perf_counter() - t0
+        rec["all_cores"] = {"value": round(st2.rays / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": many, "seconds": round(dt2, 2)}
     return rec, flops / st.rays
 
 

@@ -269,7 +269,9 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
  * it, later passes continue it in sample order, the pass that reaches spp_total divides by spp_total as
  * R/main.cpp:193 does), so any split into passes yields the floats of rt_render_device(spp_total).
  * Between passes the buffer holds sums: divide by the samples so far to display it.
- * rt_render_device(.., spp, ..) = rt_render_pass_device(.., spp, 0, spp, ..). */
+ * rt_render_device(.., spp, ..) = rt_render_pass_device(.., spp, 0, spp, ..).
+ * Both calls only enqueue work on hip_stream.  The library keeps the per-call device state (inverted camera,
+ * tile launch order) in rings of 64 and 8 slots: at most 8 render calls may be in flight at once. */
 int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h,
                           uint32_t spp_pass, uint32_t sample0, uint32_t spp_total, uint32_t seed,
                           uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,

@@ -594,11 +594,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
 struct Rng {
     uint32_t key, k;
     /* (float)rand() / RAND_MAX with RAND_MAX converted to float = 2^31 (R/src/Scene.h:259-260) */
-#if defined(RT_ABLATE) && (RT_ABLATE & 8)
-    RT_DEV float unit() { key = key * 1664525u + 1013904223u; ++k; return (float)(int)(key >> 1) / 2147483648.f; }
-#else
     RT_DEV float unit() { return (float)(int)rt_rand31(key, k++) / 2147483648.f; }
-#endif
 };
 
 /* powf(x, y) for x >= 0 through double: x^16 (the Cornell shininess) by four exact-enough double
@@ -654,25 +650,12 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                         f3 SP = S - P;
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
-#if defined(RT_ABLATE) && (RT_ABLATE & 4)
-                        Ld[j] = L[j];
-#else
                         Ld[j] = norm3(L[j]); /* Ray() normalises L again */
-#endif
                     }
-#if defined(RT_ABLATE) && (RT_ABLATE & 1)
-                    for (int j = 0; j < RT_SB; ++j) { occ[j] = false; asm volatile("" ::"v"(Ld[j].x), "v"(dist[j])); }
-                    cnt.rays += RT_SB;
-#else
                     shadow_batch<M>(sc, so, so_inside, Ld, dist, occ, cnt);
-#endif
 #pragma unroll
                     for (int j = 0; j < RT_SB; ++j)
-#if defined(RT_ABLATE) && (RT_ABLATE & 2)
-                        if (!occ[j]) { sum.x += L[j].x; asm volatile("" ::"v"(L[j].y), "v"(L[j].z)); }
-#else
                         if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
-#endif
                 }
             } else
                 for (int i = 0; i < 16; ++i) {
