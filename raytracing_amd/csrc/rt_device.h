@@ -502,7 +502,7 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
  * Every value is still produced by the reference's operations in the reference's order; the
  * answer per ray is "the closest hit exists and its t < dist", i.e. some object reports t < dist. */
 #ifndef RT_SB
-#define RT_SB 2
+#define RT_SB 4
 #endif
 template <int M>
 RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[RT_SB], const float dist[RT_SB], bool occ[RT_SB], Cnt& cnt) {
