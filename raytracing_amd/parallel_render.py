@@ -50,39 +50,68 @@ class TileLayout:
 
 
 class ShardedRenderer:
-    """rank / world from torch.distributed (or 0 / 1 when it is not initialised)."""
+    """rank / world from torch.distributed (or 0 / 1 when it is not initialised).
 
-    def __init__(self, w, h, tile_w, tile_h, device, render_tiles_fn):
+    step() renders frame i into one of two tile buffers and starts its gather without waiting for it, then
+    finishes frame i-1 (waits for that gather, scatters it to the row-major image on rank 0): the exchange of
+    one frame runs while the next one renders.  flush() finishes the frame still in flight.  With
+    pipelined=False every step() finishes its own frame."""
+
+    def __init__(self, w, h, tile_w, tile_h, device, render_tiles_fn, pipelined=True):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.layout = TileLayout(w, h, tile_w, tile_h, self.world)
         self.device = device
         self.render_tiles_fn = render_tiles_fn
-        self.mine = torch.zeros(self.layout.buffer_floats(), dtype=torch.float32, device=device)
-        self.gathered = None
+        self.pipelined = pipelined and self.world > 1
+        nbuf = 2 if self.pipelined else 1
+        self.mine = [torch.zeros(self.layout.buffer_floats(), dtype=torch.float32, device=device) for _ in range(nbuf)]
+        self.gathered_flat = [None] * nbuf
+        self.gathered = [None] * nbuf
         self.image = None
         self.perm = None
+        self.frame = 0
+        self.pending = None  # (work, buffer index) of the frame whose gather is in flight
         if self.rank == 0:
             if self.world > 1:
-                # one block, rank-major: the gather writes into its slices, no concatenation afterwards
-                self.gathered_flat = torch.empty(self.world * self.mine.numel(), dtype=torch.float32, device=device)
-                self.gathered = list(self.gathered_flat.chunk(self.world))
+                # one block per buffer, rank-major: the gather writes into its slices, no concatenation afterwards
+                for k in range(nbuf):
+                    self.gathered_flat[k] = torch.empty(self.world * self.mine[k].numel(), dtype=torch.float32, device=device)
+                    self.gathered[k] = list(self.gathered_flat[k].chunk(self.world))
             self.image = torch.zeros(h * w * 3, dtype=torch.float32, device=device)
             self.perm = torch.from_numpy(self.layout.scatter_index()).to(device)
 
-    def step(self):
-        """Render this rank's tiles, gather on rank 0, scatter to the image.  Returns the image view on
-        rank 0 (h, w, 3) and None elsewhere.  Everything is enqueued on the current stream."""
-        self.render_tiles_fn(self.mine, self.rank, self.world)
-        if self.world > 1:
-            dist.gather(self.mine, self.gathered, dst=0)
-            if self.rank != 0:
-                return None
-            src = self.gathered_flat
-        else:
-            src = self.mine
+    def _finish(self, pending):
+        """Wait (on the current stream) for a frame's gather and scatter it; the image view on rank 0, else None."""
+        work, k = pending
+        if work is not None:
+            work.wait()
+        if self.rank != 0:
+            return None
+        src = self.gathered_flat[k] if self.world > 1 else self.mine[k]
         torch.index_select(src.view(-1, 3), 0, self.perm, out=self.image.view(-1, 3))
         return self.image.view(self.layout.h, self.layout.w, 3)
+
+    def step(self):
+        """Render this rank's tiles of the next frame and start its gather.  Returns the image (h, w, 3) of the
+        frame finished by this call on rank 0 -- the previous frame when pipelined, None for the first call --
+        and None on the other ranks.  Everything is enqueued on the current stream."""
+        k = self.frame % len(self.mine)
+        self.frame += 1
+        self.render_tiles_fn(self.mine[k], self.rank, self.world)
+        work = None
+        if self.world > 1:
+            work = dist.gather(self.mine[k], self.gathered[k], dst=0, async_op=True)
+        if not self.pipelined:
+            return self._finish((work, k))
+        prev, self.pending = self.pending, (work, k)
+        # finishing frame i-1 here also keeps frame i+1 from overwriting a buffer whose gather still runs
+        return self._finish(prev) if prev is not None else None
+
+    def flush(self):
+        """Finish the frame still in flight (pipelined mode); returns its image on rank 0."""
+        prev, self.pending = self.pending, None
+        return self._finish(prev) if prev is not None else None
 
 
 def device_render_fn(scene, cam, w, h, spp, seed, tile_w, tile_h, counters=None):

@@ -39,12 +39,33 @@ def _worker(rank, world, port, w, h, tw, th, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        r = ShardedRenderer(w, h, tw, th, torch.device("cpu"), fake_render_fn(w, h, tw, th))
-        img = None
-        for _ in range(2):  # two steps: buffers are reused
-            img = r.step()
+        ok = True
+        for pipelined in (False, True):
+            frame = {"i": 0}
+            inner = fake_render_fn(w, h, tw, th)
+
+            def fn(out, r_, wd):  # frame i is the known image + i, so a stale or mixed-up buffer shows
+                inner(out, r_, wd)
+                out += float(frame["i"])
+                frame["i"] += 1
+            r = ShardedRenderer(w, h, tw, th, torch.device("cpu"), fn, pipelined=pipelined)
+            got = []
+            for _ in range(5):  # five frames: both tile buffers are reused
+                img = r.step()
+                if img is not None:
+                    got.append(img.numpy().copy())
+            last = r.flush()
+            if last is not None:
+                got.append(last.numpy().copy())
+            if rank == 0:
+                ok = ok and len(got) == 5
+                inside = expected_image(w, h)
+                for i, g_ in enumerate(got):
+                    ok = ok and bool(np.array_equal(g_, inside + np.float32(i)))
+            else:
+                ok = ok and not got
         if rank == 0:
-            q.put(bool(np.array_equal(img.numpy(), expected_image(w, h))))
+            q.put(ok)
         dist.barrier()
     finally:
         dist.destroy_process_group()
