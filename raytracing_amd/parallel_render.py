@@ -80,6 +80,10 @@ class ShardedRenderer:
                     self.gathered[k] = list(self.gathered_flat[k].chunk(self.world))
             self.image = torch.zeros(h * w * 3, dtype=torch.float32, device=device)
             self.perm = torch.from_numpy(self.layout.scatter_index()).to(device)
+        if self.world > 1:
+            # set-up, not a frame: the first gather opens the point-to-point channels to rank 0 (tens of ms on RCCL)
+            probe = torch.zeros(1, dtype=torch.float32, device=device)
+            dist.gather(probe, [torch.zeros_like(probe) for _ in range(self.world)] if self.rank == 0 else None, dst=0)
 
     def _finish(self, pending):
         """Wait (on the current stream) for a frame's gather and scatter it; the image view on rank 0, else None."""
