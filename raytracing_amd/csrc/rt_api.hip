@@ -6,7 +6,9 @@
  *                    its whole path tree; the wave then adds its lanes' colours in sample order
  *                    (the reference's float summation order, R/main.cpp:185-193) and lane 0
  *                    stores the pixel.  Lanes of a wave share a pixel, so they follow almost the
- *                    same path and the scalar-cached scene tables stay wave-uniform.
+ *                    same path and the scalar-cached scene tables stay wave-uniform.  With 32 or
+ *                    fewer samples per pixel a wave takes 64 / spp pixels instead.
+ *   k_tile_class, k_tile_place   before each render: order the tiles by their deepest path tree.
  *   k_intersect      one lane per ray: Scene::computeIntersection.
  *   k_mesh_intersect one lane per ray: Mesh::intersect of one mesh.
  *   k_trace          one lane per ray: Scene::rayTrace under the counter RNG.
@@ -63,6 +65,9 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     }
 }
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4 /* waves per SIMD the render variants are compiled for (<= 128 VGPRs) */
+#endif
 #ifdef RT_WAVES_PER_EU
 #define RT_OCC __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #else
@@ -75,8 +80,9 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
  * rim pixel started at 2 ms stretched a 4.2 ms launch of one eighth of the frame to 5.3 ms).  So
  * before each render one wave per tile walks the path tree of the centre ray of every pixel of
  * the tile without shading it, and the tiles are launched in the order of their deepest tree
- * (capped at RT_PROBE_CAP nodes, where an ordinary glass pixel has 16-21; counting sort in k_tile_place).  The order only changes WHEN a
- * tile is rendered: pixel values, RNG streams and the output layout depend on the tile id alone.
+ * (capped at RT_PROBE_CAP nodes, where an ordinary glass pixel has 16-21; counting sort in
+ * k_tile_place).  The order only changes WHEN a tile is rendered: pixel values, RNG streams and
+ * the output layout depend on the tile id alone.
  * Workspace (uint32): [0, n) key of local tile i (0 = deepest), [n, 2n) the order. */
 #define RT_ORDER_KEYS (RT_PROBE_CAP + 1)
 template <int M>
@@ -141,7 +147,7 @@ extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
  * PACK = true : spp <= 32, 64 / spp pixels per wave, lane = (pixel, sample), so that few samples
  *               per pixel do not leave most lanes idle. */
 template <int M, bool PACK>
-__global__ __launch_bounds__(256, 4) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
+__global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters, const uint32_t* __restrict__ order) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
