@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
             primary_ray(cam, u, v, &o, &d);
-            col = trace_path<M>(sc, o, norm3(d), rng, cnt);
+            col = trace_path<M>(sc, o, norm3_unit(d), rng, cnt);
             ++my_samples;
         }
         for (uint32_t i = 0; i < rp.spp; ++i) { /* every lane of the wave takes part in the shuffles */
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene
                 float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
                 f3 o, d;
                 primary_ray(cam, u, v, &o, &d);
-                col = trace_path<M>(sc, o, norm3(d), rng, cnt); /* Ray(pos, dir) normalises again */
+                col = trace_path<M>(sc, o, norm3_unit(d), rng, cnt); /* Ray(pos, dir) normalises again */
                 ++my_samples;
             }
             /* image[x + y*w] += color, one sample after the other */
@@ -315,6 +315,26 @@ __global__ __launch_bounds__(256) void k_selftest_arith(uint64_t n, uint32_t see
                 __float_as_int(f.y) == __float_as_int(r.y) && __float_as_int(f.z) == __float_as_int(r.z);
     bool both_nan = (L_ref != L_ref) && (L_fast != L_fast);
     if (!same && !both_nan) atomicAdd(mismatches, 1ull);
+
+    /* norm3_unit: (a) every sum of squares of its window against the IEEE square root (the first 8193 threads
+     * cover the window, the next ones a margin on both sides that must take the ordinary path) */
+    if (i < 8193 + 64) {
+        float q = __int_as_float(0x3f800000 - 4096 - 32 + (int)i);
+        /* a vector whose sum of squares is exactly q: (sqrt-free) one component carries everything */
+        float L_bits = __int_as_float((__float_as_int(q) >> 1) + 0x1fc00000);
+        bool inside = (uint32_t)(__float_as_int(q) - (0x3f800000 - 4096)) <= 8192u;
+        if (inside && __float_as_int(L_bits) != __float_as_int(__builtin_sqrtf(q))) atomicAdd(mismatches, 1ull);
+    }
+    /* (b) the vector above normalised once with the IEEE operators is unit up to rounding: normalising it
+     * again both ways must agree bit for bit (tiny and zero components included) */
+    if (L_ref > 0.f && L_ref < 0x1p60f) {
+        f3 u1 = r;
+        float L2 = __builtin_sqrtf(u1.x * u1.x + u1.y * u1.y + u1.z * u1.z);
+        f3 want = mk3(u1.x / L2, u1.y / L2, u1.z / L2), got = norm3_unit(u1);
+        bool ok = __float_as_int(want.x) == __float_as_int(got.x) && __float_as_int(want.y) == __float_as_int(got.y) &&
+                  __float_as_int(want.z) == __float_as_int(got.z);
+        if (!ok && L2 == L2) atomicAdd(mismatches, 1ull);
+    }
 }
 
 /* ======================================================================================== */

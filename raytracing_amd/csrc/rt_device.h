@@ -78,6 +78,25 @@ RT_DEV f3 norm3_len(f3 a, float& L) {
     return mk3(a.x / L, a.y / L, a.z / L);
 }
 RT_DEV f3 norm3(f3 a) { float L; return norm3_len(a, L); }
+/* normalize() of a vector that is already unit length up to rounding (the Ray constructor's second
+ * normalisation, a mirrored or refracted unit direction, a stored normal): same result as norm3, cheaper
+ * when q = x^2 + y^2 + z^2 lies within 4096 float steps of 1.  There the correctly rounded square root
+ * follows from the bit pattern alone: q = 1 + m 2^-23 has sqrt 1 + (m/2) 2^-23 - m^2 2^-48 + ..., which
+ * rounds to 1 + floor(m/2) 2^-23 (the second-order term, < 2^-25, only decides the halfway case, downwards);
+ * q = 1 - k 2^-24 has sqrt 1 - (k/2) 2^-24 - k^2 2^-51 - ..., which rounds to 1 - ceil(k/2) 2^-24.  Both
+ * are bits(L) = (bits(q) >> 1) + 0x1fc00000 (arithmetic: 0x3f800000 is even, so halving the distance from
+ * it with floor rounding is one shift).  The quotients are those of norm3_len.  The device self-test
+ * checks every q of that window against the IEEE square root. */
+RT_DEV f3 norm3_unit(f3 a) {
+    float q = a.x * a.x + a.y * a.y + a.z * a.z;
+    float lo = fminf(fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    if ((uint32_t)(__float_as_int(q) - (0x3f800000 - 4096)) <= 8192u && lo >= 0x1p-40f) {
+        float L = __int_as_float((__float_as_int(q) >> 1) + 0x1fc00000);
+        float r = rcp_refined(L);
+        return mk3(div_plain(a.x, L, r), div_plain(a.y, L, r), div_plain(a.z, L, r));
+    }
+    return norm3(a);
+}
 RT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 RT_DEV float max_std(float a, float b) { return (a < b) ? b : a; } /* std::max, NaN behaviour included */
 RT_DEV float min_std(float a, float b) { return (b < a) ? b : a; } /* std::min */
@@ -608,7 +627,7 @@ RT_DEV float pow_shiny(float x, float y) {
 
 /* Scene::computeLightContribution, R/src/Scene.h:304-316 */
 RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V, f3 L) {
-    f3 R = norm3((2.f * dot3(N, L)) * N - L);
+    f3 R = norm3_unit((2.f * dot3(N, L)) * N - L);
     float nl = max_std(0.f, dot3(L, N));
     float sp = pow_shiny(max_std(0.f, dot3(R, V)), m.shininess);
     sum.x += lt.color[0] * m.kd[0] * nl; sum.x += lt.color[0] * m.ks[0] * sp;
@@ -628,7 +647,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     f3 ambient = 0.35f * mk3(0.2f, 0.2f, 0.2f);
     f3 diffuse = mk3(0.f, 0.f, 0.f), specular = mk3(0.f, 0.f, 0.f);
     const f3 P = h.p;
-    const f3 N = norm3(h.n);
+    const f3 N = norm3_unit(h.n);
     const f3 V = norm3(-1.f * P);              /* camera assumed at the world origin */
     const f3 so = P + 0.001f * N;              /* shadow-ray origin */
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
@@ -650,7 +669,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                         f3 SP = S - P;
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
-                        Ld[j] = norm3(L[j]); /* Ray() normalises L again */
+                        Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
                     shadow_batch<M>(sc, so, so_inside, Ld, dist, occ, cnt);
 #pragma unroll
@@ -665,7 +684,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                     f3 SP = S - P;
                     f3 L = norm3(SP);
-                    if (occluded<M>(sc, so, norm3(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
+                    if (occluded<M>(sc, so, norm3_unit(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
                     light_term(sum, lt, m, N, V, L);
                 }
             sum = sum / 16.f;
@@ -674,7 +693,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
         } else {
             f3 SP = ld3(lt.pos) - P;
             f3 L = norm3(SP);
-            if (occluded<M>(sc, so, norm3(L), len3(SP), cnt)) continue;
+            if (occluded<M>(sc, so, norm3_unit(L), len3(SP), cnt)) continue;
             light_term(diffuse, lt, m, N, V, L);
         }
     }
@@ -716,7 +735,7 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
                     f3 R = I - (2.0f * dot3(I, N)) * N;
                     float* f = stk[sp++];
                     f[0] = 1.f; f[1] = 0.f; f[2] = col.x; f[3] = col.y; f[4] = col.z; f[5] = m.ks[0]; f[6] = m.ks[1]; f[7] = m.ks[2];
-                    o = P + 0.001f * N; d = norm3(R);
+                    o = P + 0.001f * N; d = norm3_unit(R);
                     descended = true;
                 } else if (m.type == RT_MAT_GLASS) {
                     float n1 = 1.0f, n2 = m.ior;
@@ -738,10 +757,10 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
                     f[1] = F;
                     if (F < 1.0f) {
                         f3 T = eta * (I - cosI * N) - __builtin_sqrtf(1.0f - sinT2) * N;
-                        f3 to = P - 0.001f * N, td = norm3(T);
+                        f3 to = P - 0.001f * N, td = norm3_unit(T);
                         f[0] = 2.f; f[2] = to.x; f[3] = to.y; f[4] = to.z; f[5] = td.x; f[6] = td.y; f[7] = td.z;
                     } else f[0] = 3.f;
-                    o = P + 0.001f * N; d = norm3(R);
+                    o = P + 0.001f * N; d = norm3_unit(R);
                     descended = true;
                 }
             }
