@@ -534,25 +534,35 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
         occ[j] = false;
     }
     /* tables walked directly with one-ahead record fetches, as in root_closest */
+    /* Per object the cheap part runs for all rays of the batch first, in straight-line code, and the rare
+     * expensive part sits behind ONE wave-level branch per object instead of one per ray. */
     for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& s, uint32_t) {
         f3 oc = o - ld3(s.c);
         float n = len3(oc);
         float c = (n * n) - s.r2;
+        float b[RT_SB], delta[RT_SB];
+        bool some = false;
 #pragma unroll
         for (int j = 0; j < RT_SB; ++j) {
             float a = dot3(d[j], d[j]);
-            float b = dot3(2.f * d[j], oc);
-            float delta = b * b - 4.f * a * c;
+            b[j] = dot3(2.f * d[j], oc);
+            delta[j] = b[j] * b[j] - 4.f * a * c;
+            some = some || delta[j] >= 0.f;
+        }
+        if (!some) return; /* every line of the batch misses the sphere */
+#pragma unroll
+        for (int j = 0; j < RT_SB; ++j) {
+            float a = dot3(d[j], d[j]);
             float t = RT_INF; /* stays +inf (never < dist) when the sphere is missed */
-            if (delta > 0.f) {
-                float sq = __builtin_sqrtf(delta);
+            if (delta[j] > 0.f) {
+                float sq = __builtin_sqrtf(delta[j]);
                 float a2 = 2.f * a;
-                float t1 = (-b - sq) / a2, t2 = (-b + sq) / a2;
+                float t1 = (-b[j] - sq) / a2, t2 = (-b[j] + sq) / a2;
                 if (t1 > 0.f && t2 > 0.f) t = min_std(t1, t2);
                 else if (t1 > 0.f) t = t1;
                 else if (t2 > 0.f) t = t2;
-            } else if (delta == 0.f) {
-                float t0 = -b / (2.f * a);
+            } else if (delta[j] == 0.f) {
+                float t0 = -b[j] / (2.f * a);
                 if (t0 > 0.f) t = t0;
             }
             occ[j] = occ[j] || (t < dist[j]);
@@ -569,15 +579,20 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t) {
         f3 v0 = ld3(q.v0), n = ld3(q.n);
         float num = dot3(v0 - o, n);
+        bool maybe[RT_SB], some = false;
 #pragma unroll
         for (int j = 0; j < RT_SB; ++j) {
-            float den = dot3(d[j], n);
-            float ta = num * __builtin_amdgcn_rcpf(den);
-            if (!(ta < -1e-30f) && !(ta > dist_hi[j])) {
-                float tt = num / den;
+            float ta = num * __builtin_amdgcn_rcpf(dot3(d[j], n));
+            maybe[j] = !(ta < -1e-30f) && !(ta > dist_hi[j]);
+            some = some || maybe[j];
+        }
+        if (!some) return;
+#pragma unroll
+        for (int j = 0; j < RT_SB; ++j)
+            if (maybe[j]) {
+                float tt = num / dot3(d[j], n);
                 if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
             }
-        }
     });
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
         const DMesh m = ldc(&sc.meshes[mi]);
