@@ -21,7 +21,7 @@ for k in sorted(c):
 if a.rays and "SQ_INSTS_VALU" in c:
     print(f"\nVALU wave-instructions per 64 rays : {c['SQ_INSTS_VALU'] * 64 / a.rays:.1f}")
     if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
-        print(f"mean active lanes per VALU instr   : {c['SQ_THREAD_CYCLES_VALU'] / c['SQ_ACTIVE_INST_VALU'] / 4:.1f} of 64 (thread-cycles / active quad-cycles / 4)")
+        print(f"mean active lanes per VALU instr   : {c['SQ_THREAD_CYCLES_VALU'] / c['SQ_ACTIVE_INST_VALU']:.1f} of 64 (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU)")
 if a.ms and "GRBM_GUI_ACTIVE" in c:
     clk = c["GRBM_GUI_ACTIVE"] / 8 / (a.ms * 1e-3)
     print(f"shader clock                       : {clk / 1e9:.2f} GHz")
