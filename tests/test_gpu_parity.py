@@ -196,7 +196,7 @@ def test_packed_lanes_match_the_oracle_for_every_small_spp():
     g = api.DeviceScene(o.desc, keep=o)
     w, h = 37, 21
     cam = orc.camera_default(w, h)
-    for spp in (1, 2, 3, 5, 7, 8, 13, 21, 32, 33):
+    for spp in (1, 2, 3, 5, 7, 8, 13, 21, 32, 33, 50, 63, 64, 65, 100, 130):  # above 32: cut into 64s, a 32 and a rest
         gi, gst = g.render(cam, w, h, spp, seed=spp, tile_w=5, tile_h=3)
         oi, ost = o.render(cam, w, h, spp, orc.RT_RNG_COUNTER, spp)
         assert gst.rays == ost.rays and gst.samples == ost.samples == w * h * spp
