@@ -251,22 +251,28 @@ RT_DEV bool slab(const float lo[3], const float hi[3], f3 o, f3 id, float limit,
     float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), limit));
     return tn <= tf;
 }
+/* Can the ray come near the mesh at all?  A division-free test against the mesh's bounding sphere (b and c2
+ * carry a rounding error of a few 2^-24 * c2, d is unit to 2^-23: the 1e-6 * c2 slack keeps every rejection
+ * certain; NaN / inf operands reject nothing), then the padded root box.  limit = FLT_MAX for a closest-hit
+ * query, the distance to the light for a shadow ray. */
+RT_DEV f3 bvh_inv_dir(f3 d) { return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 template <bool ANY>
-RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
-                         float& best_u, float& best_v) {
+RT_DEV bool bvh_reaches(const DMesh& m, f3 o, f3 d, float limit) {
+    const f3 oc = ld3(m.bs_c) - o;
+    const float b = dot3(oc, d), c2 = dot3(oc, oc);
+    const float r2 = m.bs_r2 + 1e-6f * c2;
+    if (c2 - b * b > r2) return false;   /* the line misses the sphere */
+    if (b < 0.f && c2 > r2) return false; /* the sphere lies behind the origin */
+    if (ANY && b > limit) { const float e = b - limit; if (e * e > r2) return false; } /* ... or beyond the light */
+    float tn;
+    return slab(m.lo, m.hi, o, bvh_inv_dir(d), limit, tn);
+}
+/* The traversal proper; the caller has checked bvh_reaches. */
+template <bool ANY>
+RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
+                     float& best_u, float& best_v) {
     best_t = ANY ? dist : 3.402823466e+38f; /* FLT_MAX, the reference's initial closest t */
-    { /* Division-free early out against the mesh's bounding sphere (most rays of a scene never come
-       * near a given mesh).  b and c2 carry a rounding error of a few 2^-24 * c2, d is unit to 2^-23:
-       * the 1e-6 * c2 slack keeps every rejection certain.  NaN / inf operands reject nothing. */
-        const f3 oc = ld3(m.bs_c) - o;
-        const float b = dot3(oc, d), c2 = dot3(oc, oc);
-        const float r2 = m.bs_r2 + 1e-6f * c2;
-        if (c2 - b * b > r2) return false;   /* the line misses the sphere */
-        if (b < 0.f && c2 > r2) return false; /* the sphere lies behind the origin */
-        if (ANY && b > dist) { const float e = b - dist; if (e * e > r2) return false; } /* ... or beyond the light */
-    }
-    const f3 id = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    { float tn; if (!slab(m.lo, m.hi, o, id, best_t, tn)) return false; }
+    const f3 id = bvh_inv_dir(d);
     int sp = 0;
     bool found = false;
     uint32_t best_orig = 0xffffffffu;
@@ -314,6 +320,14 @@ RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, floa
         }
     }
     return found;
+}
+
+template <bool ANY>
+RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
+                         float& best_u, float& best_v) {
+    best_t = ANY ? dist : 3.402823466e+38f;
+    if (!bvh_reaches<ANY>(m, o, d, best_t)) return false;
+    return bvh_walk<ANY>(sc, m, o, d, dist, cnt, best_t, best_tri, best_u, best_v);
 }
 
 /* ---- Mesh::intersect closest loop, R/src/Mesh.h:225-277 (brute force over the slice) ----- */
@@ -596,10 +610,21 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     });
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
         const DMesh m = ldc(&sc.meshes[mi]);
-        if ((M & RT_M_BVH) && m.bvh_root >= 0) { /* large mesh: one BVH traversal per ray */
+        if ((M & RT_M_BVH) && m.bvh_root >= 0) { /* large mesh: one BVH traversal per ray that comes near it */
+            bool go[RT_SB], some = false;
 #pragma unroll
-            for (int j = 0; j < RT_SB; ++j)
-                if (!occ[j] && act[j] && mesh_any<M>(sc, m, o, d[j], dist[j], cnt)) occ[j] = true;
+            for (int j = 0; j < RT_SB; ++j) {
+                go[j] = !occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j]);
+                some = some || go[j];
+            }
+            if (some) {
+#pragma unroll
+                for (int j = 0; j < RT_SB; ++j) {
+                    float t, u, v;
+                    int tri;
+                    if (go[j] && bvh_walk<true>(sc, m, o, d[j], dist[j], cnt, t, tri, u, v)) occ[j] = true;
+                }
+            }
             continue;
         }
         for_each_record(sc.tris + m.first_tri, m.n_tris, [&](const DTri& tr, uint32_t) {
