@@ -611,20 +611,27 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
         const DMesh m = ldc(&sc.meshes[mi]);
         if ((M & RT_M_BVH) && m.bvh_root >= 0) { /* large mesh: one BVH traversal per ray that comes near it */
-            bool go[RT_SB], some = false;
+            /* Few rays of a batch come near the mesh, and in different lanes they are different rays.  Each
+             * lane queues its own (pend) and all lanes walk their next queued ray together: the number of
+             * walks a wave pays for is the longest queue, not one per ray index somebody needs. */
+            uint32_t pend = 0, hit = 0;
 #pragma unroll
-            for (int j = 0; j < RT_SB; ++j) {
-                go[j] = !occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j]);
-                some = some || go[j];
-            }
-            if (some) {
+            for (int j = 0; j < RT_SB; ++j)
+                if (!occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j])) pend |= 1u << j;
+            while (pend) {
+                const int j = __builtin_ctz(pend);
+                pend &= pend - 1;
+                f3 dj = d[0];
+                float distj = dist[0];
 #pragma unroll
-                for (int j = 0; j < RT_SB; ++j) {
-                    float t, u, v;
-                    int tri;
-                    if (go[j] && bvh_walk<true>(sc, m, o, d[j], dist[j], cnt, t, tri, u, v)) occ[j] = true;
-                }
+                for (int k = 1; k < RT_SB; ++k)
+                    if (j == k) { dj = d[k]; distj = dist[k]; }
+                float t, u, v;
+                int tri;
+                if (bvh_walk<true>(sc, m, o, dj, distj, cnt, t, tri, u, v)) hit |= 1u << j;
             }
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j) occ[j] = occ[j] || ((hit >> j) & 1u);
             continue;
         }
         for_each_record(sc.tris + m.first_tri, m.n_tris, [&](const DTri& tr, uint32_t) {
