@@ -285,6 +285,16 @@ void rt_counters_total(const uint64_t* h_counters, uint64_t out5[5]);
 int rt_tiles_to_image(const float* gathered, uint32_t w, uint32_t h, uint32_t tile_w,
                       uint32_t tile_h, uint32_t world, float* rgb_image);
 
+/* ---- image output (R/main.cpp:204-216) ------------------------------------------------------
+ * rt_tiles_to_rgb8_device: what rt_tiles_to_image does, on the device and fused with the reference's
+ * quantisation (int)(255.f * min(1.f, c)) (R/main.cpp:213): gathered tile buffers (rank-major, each padded
+ * to the tile count of rank 0) -> row-major 8-bit RGB, 3 * w * h bytes.  Enqueued on hip_stream.
+ * rt_write_ppm: 8-bit RGB to a PPM file; binary = 0 writes the reference's ASCII P3 layout (header lines
+ * "P3", "w h", "255", then "r g b " per pixel and a final newline), binary = 1 the same pixels as P6. */
+int rt_tiles_to_rgb8_device(const float* d_gathered, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h,
+                            uint32_t world, uint8_t* d_rgb8, void* hip_stream);
+int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h, int binary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
 # every symbol include/rtamd.h declares
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
-           "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_tiles_to_image", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
+           "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
 _lib = None
 
@@ -106,6 +106,8 @@ def lib():
         L.rt_render_device.argtypes = [u64, C.POINTER(Camera)] + [u32] * 8 + [vp, vp, vp]
         L.rt_render_pass_device.argtypes = [u64, C.POINTER(Camera)] + [u32] * 10 + [vp, vp, vp]
         L.rt_tiles_to_image.argtypes = [vp, u32, u32, u32, u32, u32, vp]
+        L.rt_tiles_to_rgb8_device.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp]
+        L.rt_write_ppm.argtypes = [C.c_char_p, vp, u32, u32, C.c_int]
         L.rt_selftest_arith.argtypes = [u64, u32, C.POINTER(u64)]
         L.rt_normalize_dirs.argtypes = [vp, C.c_size_t, vp]
         _lib = L
@@ -224,6 +226,18 @@ class DeviceScene:
         cam = cam if isinstance(cam, Camera) else copy_struct(Camera, cam)
         check(lib().rt_render_pass_device(self.h, C.byref(cam), w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank,
                                           world, C.c_void_p(d_out_ptr), C.c_void_p(d_counters_ptr), C.c_void_p(stream_ptr)))
+
+
+def tiles_to_rgb8_device(d_gathered_ptr, w, h, tile_w, tile_h, world, d_rgb8_ptr, stream_ptr):
+    """Un-tile + quantise on the device (raw pointers as ints), enqueued on the stream."""
+    check(lib().rt_tiles_to_rgb8_device(C.c_void_p(d_gathered_ptr), w, h, tile_w, tile_h, world, C.c_void_p(d_rgb8_ptr),
+                                        C.c_void_p(stream_ptr)))
+
+
+def write_ppm(path, rgb8, binary=True):
+    """rgb8: (h, w, 3) uint8 -> P6 (binary) or the reference's ASCII P3 layout."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    check(lib().rt_write_ppm(os.fsencode(path), _ptr(rgb8), rgb8.shape[1], rgb8.shape[0], 1 if binary else 0))
 
 
 def scene_check(desc):

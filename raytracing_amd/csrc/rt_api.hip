@@ -224,6 +224,19 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene
 #endif
     flush_counters<M>(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
 }
+/* one thread per pixel: find the pixel in the rank-major tile buffers, quantise like R/main.cpp:213 */
+__global__ __launch_bounds__(256) void k_tiles_to_rgb8(const float* __restrict__ tiles, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h,
+                                                       uint32_t tiles_x, uint32_t world, uint32_t per_rank, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint64_t)w * h) return;
+    const uint32_t x = (uint32_t)(i % w), y = (uint32_t)(i / w);
+    const uint32_t ty = y / tile_h, tx = x / tile_w;
+    const uint32_t t = ty * tiles_x + (tx + tiles_x - ty % tiles_x) % tiles_x; /* inverse of rt_tile_column */
+    const uint64_t px = ((uint64_t)(t % world) * per_rank + t / world) * tile_w * tile_h + (uint64_t)(y % tile_h) * tile_w + x % tile_w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[3 * i + c] = (uint8_t)(int)(255.f * min_std(1.f, tiles[3 * px + c]));
+}
+
 RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u, float v) {
     rt_hit r;
     r.hit = h.hit ? 1 : 0;
@@ -852,6 +865,43 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
         stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4];
     }
     return RT_OK;
+}
+
+int rt_tiles_to_rgb8_device(const float* d_gathered, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t world,
+                            uint8_t* d_rgb8, void* hip_stream) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_tiles_to_rgb8_device: call rt_init first");
+    if (!d_gathered || !d_rgb8 || !w || !h || !tile_w || !tile_h || !world) return fail(RT_E_INVALID, "rt_tiles_to_rgb8_device: bad argument");
+    if ((uint64_t)w * h > 0x7fffffffull) return fail(RT_E_LIMIT, "rt_tiles_to_rgb8_device: more than 2^31 pixels");
+    const uint32_t tiles_x = (w + tile_w - 1) / tile_w;
+    const uint32_t per_rank = (uint32_t)rt_tiles_per_rank(w, h, tile_w, tile_h, 0, world);
+    hipLaunchKernelGGL(k_tiles_to_rgb8, dim3(blocks_for((size_t)w * h)), dim3(256), 0, (hipStream_t)hip_stream, d_gathered, w, h, tile_w, tile_h,
+                       tiles_x, world, per_rank, d_rgb8);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h, int binary) {
+    if (!path || !rgb8 || !w || !h) return fail(RT_E_INVALID, "rt_write_ppm: bad argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RT_E_INVALID, std::string("rt_write_ppm: could not open ") + path);
+    const size_t n = (size_t)w * h;
+    bool ok;
+    if (binary) {
+        ok = std::fprintf(f, "P6\n%u %u\n255\n", w, h) > 0 && std::fwrite(rgb8, 3, n, f) == n;
+    } else {
+        ok = std::fprintf(f, "P3\n%u %u\n255\n", w, h) > 0;
+        std::string line;
+        line.reserve(n * 12 + 2);
+        for (size_t i = 0; i < n; ++i) {
+            char buf[16];
+            int k = std::snprintf(buf, sizeof buf, "%u %u %u ", (unsigned)rgb8[3 * i], (unsigned)rgb8[3 * i + 1], (unsigned)rgb8[3 * i + 2]);
+            line.append(buf, (size_t)k);
+        }
+        line.push_back('\n');
+        ok = ok && std::fwrite(line.data(), 1, line.size(), f) == line.size();
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : fail(RT_E_INVALID, std::string("rt_write_ppm: write failed on ") + path);
 }
 
 int rt_tiles_to_image(const float* gathered, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t world, float* rgb_image) {

@@ -25,8 +25,21 @@ inline bool write_ppm_p3(const std::string& filename, const std::vector<Vec3>& i
     return true;
 }
 
+/* the same pixels as binary P6 (one sixth of the bytes, no text parsing for the reader) */
+inline bool write_ppm_p6(const std::string& filename, const std::vector<Vec3>& image, int w, int h) {
+    std::vector<uint8_t> rgb8((size_t)w * h * 3);
+    for (int i = 0; i < w * h; ++i)
+        for (int c = 0; c < 3; ++c) rgb8[3 * (size_t)i + c] = (uint8_t)(int)(255.f * std::min<float>(1.f, image[i][c]));
+    if (rt_write_ppm(filename.c_str(), rgb8.data(), (uint32_t)w, (uint32_t)h, 1) != 0) {
+        std::cout << "Could not open file: " << filename << std::endl;
+        return false;
+    }
+    return true;
+}
+
 inline void ray_trace_from_camera(Scene& scene, Camera& camera, unsigned nsamples = 50, uint32_t seed = 1,
-                                  const std::string& filename = "./rendu.ppm", rt_stats* stats_out = nullptr) {
+                                  const std::string& filename = "./rendu.ppm", rt_stats* stats_out = nullptr,
+                                  const std::string& filename_p6 = "") {
     int w = camera.getScreenWidth(), h = camera.getScreenHeight();
     std::cout << "Ray tracing a " << w << " x " << h << " image" << std::endl;
     auto start = std::chrono::high_resolution_clock::now();
@@ -36,6 +49,7 @@ inline void ray_trace_from_camera(Scene& scene, Camera& camera, unsigned nsample
     scene.render(camera.glState(), w, h, nsamples, seed, image, &st);
     std::cout << "\rProgress: 100% - Done!            " << std::endl;
     if (!write_ppm_p3(filename, image, w, h)) return;
+    if (!filename_p6.empty() && !write_ppm_p6(filename_p6, image, w, h)) return;
     auto end = std::chrono::high_resolution_clock::now();
     auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count();
     std::cout << "Image saved to '" << filename << "' in " << ms << " ms." << std::endl;

@@ -65,10 +65,14 @@ def test_headless_plus_and_r_keys(tmp_path):
     out = tmp_path / "rendu.ppm"
     w, h, spp = 96, 80, 3
     subprocess.run([os.path.join(HOST_DIR, "rt_main"), "--w", str(w), "--h", str(h), "--spp", str(spp), "--seed", "1", "--keys", "+r",
-                    "--out", str(out), "--off", host.STAR_OFF], check=True, capture_output=True, timeout=300)
+                    "--out", str(out), "--p6", str(tmp_path / "rendu_p6.ppm"), "--off", host.STAR_OFF], check=True, capture_output=True,
+                   timeout=300)
     toks = open(out).read().split()
     assert toks[:4] == ["P3", str(w), str(h), "255"]
     got = np.array(toks[4:], np.uint8).reshape(h, w, 3)
+    raw = open(tmp_path / "rendu_p6.ppm", "rb").read()
+    head = f"P6\n{w} {h}\n255\n".encode()
+    assert raw.startswith(head) and raw[len(head):] == got.tobytes()  # the binary file holds the same pixels
     o = orc.Scene.builtin(3)
     img, _ = o.render(orc.camera_default(w, h), w, h, spp, orc.RT_RNG_COUNTER, seed=1, threads=4)
     want = orc.quantize(img)

@@ -204,6 +204,29 @@ def test_packed_lanes_match_the_oracle_for_every_small_spp():
     g.close()
 
 
+def test_device_untile_and_quantise_matches_host_path():
+    """rt_tiles_to_rgb8_device on the gathered buffers of 3 ranks = rt_tiles_to_image + the reference's quantisation."""
+    import torch
+    o = orc.Scene.builtin(2)
+    g = api.DeviceScene(o.desc, keep=o)
+    w, h, spp, tw, th, world = 100, 37, 4, 16, 8, 3
+    cam = orc.camera_default(w, h)
+    per = api.tiles_per_rank(w, h, tw, th, 0, world)
+    buf = np.zeros((world, per * th * tw * 3), np.float32)
+    for r in range(world):
+        tiles, _ = g.render_tiles(cam, w, h, spp, 9, tw, th, r, world)
+        buf[r, :tiles.size] = tiles.ravel()
+    buf[0, :3] = [2.5, -0.25, np.nan]  # above 1, negative, NaN: whatever the CPU expression gives
+    want = orc.quantize(api.tiles_to_image(buf, w, h, tw, th, world))
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(buf).to(dev)
+    d_out = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+    api.tiles_to_rgb8_device(d_in.data_ptr(), w, h, tw, th, world, d_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().reshape(h, w, 3), want)
+    g.close()
+
+
 def test_tile_launch_order_does_not_change_the_image(tmp_path):
     """The deepest-path-first launch order of the tiles only decides when a tile is rendered: a second
     process with RTAMD_TILE_ORDER=0 (index order) produces the same floats, sharded or not."""

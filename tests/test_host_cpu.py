@@ -93,3 +93,23 @@ def test_ppm_writer_matches_reference_format(tmp_path):
     toks = open(p).read().split()
     assert toks[:4] == ["P3", "2", "1", "255"]
     assert [int(t) for t in toks[4:]] == list(orc.quantize(rgb).ravel())
+
+
+def test_rt_write_ppm_p3_and_p6(tmp_path):
+    """The C-ABI writer: P3 token for token the layout of the reference (and of host.write_ppm), P6 the same bytes."""
+    rng = np.random.default_rng(3)
+    rgb8 = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    p3, p6 = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    api.write_ppm(p3, rgb8, binary=False)
+    api.write_ppm(p6, rgb8, binary=True)
+    text = open(p3).read()
+    assert text.startswith("P3\n5 7\n255\n") and text.endswith(" \n")
+    assert [int(t) for t in text.split()[4:]] == list(rgb8.ravel())
+    raw = open(p6, "rb").read()
+    assert raw.startswith(b"P6\n5 7\n255\n") and raw[len(b"P6\n5 7\n255\n"):] == rgb8.tobytes()
+    # same P3 tokens as the host writer that follows R/main.cpp:204-216
+    ref = str(tmp_path / "c.ppm")
+    host.write_ppm(ref, rgb8.astype(np.float32) / np.float32(255.0) + np.float32(1e-4))
+    assert open(ref).read().split() == text.split()
+    with pytest.raises(api.RtError):
+        api.write_ppm(str(tmp_path / "no" / "such" / "dir.ppm"), rgb8)
