@@ -87,3 +87,27 @@ def test_description_errors_match_scene_create():
     with pytest.raises(api.RtError):
         api.lib().rt_scene_check.restype = C.c_int
         api.check(api.lib().rt_scene_check(None, None))
+
+
+def test_builder_under_address_and_ub_sanitizers(tmp_path):
+    """rt_build.cpp (validation, kd-tree, BVH, camera inversion) compiled for the host with ASan + UBSan and run
+    on ordinary, degenerate (NaN / huge coordinates, identical triangles) and invalid descriptions."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "build_harness")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+           "-I", os.path.join(root, "raytracing_amd", "csrc"), "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "sanitize", "build_harness.cpp"), os.path.join(root, "raytracing_amd", "csrc", "rt_build.cpp"),
+           "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if built.returncode != 0 and "sanitize" in built.stderr and "cannot find" in built.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert built.returncode == 0, built.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0 and run.stdout.strip().startswith("OK"), (run.stdout + run.stderr)[-3000:]
