@@ -383,6 +383,7 @@ struct SceneRes {
     rtb::Built host;
     DeviceScene dev{};
     int mode = 0;
+    bool has_bounce = false; /* some sphere is a mirror or glass: only then do path trees differ in depth */
     std::vector<void*> allocs;
 };
 
@@ -592,6 +593,10 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
     d.kd_epsilon = r->host.kd_epsilon;
     d.root_is_leaf = (!r->host.kd.empty() && r->host.kd[0].leaf) ? 1 : 0;
     r->mode = (d.root_is_leaf ? 0 : RT_M_KD) | (r->host.bvh.empty() ? 0 : RT_M_BVH);
+    for (const DSphere& sp : r->host.spheres) {
+        const int mt = r->host.materials[(size_t)sp.mat].type;
+        r->has_bounce = r->has_bounce || mt == RT_MAT_MIRROR || mt == RT_MAT_GLASS;
+    }
     rt_scene_t h = g.next_handle++;
     g.scenes[h] = r;
     *out = h;
@@ -802,7 +807,7 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
         g.cam_last = *cam;
     }
     const uint32_t* d_order = nullptr;
-    if (g.order_tiles && rp.n_local_tiles > 1) {
+    if (g.order_tiles && r->has_bounce && rp.n_local_tiles > 1) { /* without bounces every tree has one node: nothing to order */
         const unsigned slot = g.order_next++ % kOrderSlots;
         const size_t words = 2 * (size_t)rp.n_local_tiles;
         if (g.order_cap[slot] < words) {
