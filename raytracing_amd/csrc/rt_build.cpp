@@ -208,6 +208,36 @@ struct BvhBuilder {
     }
 };
 
+/* Padded box and bounding sphere of a mesh's (scaled) triangles: what a ray has to come near before any of its
+ * triangles can report a hit.  The pad covers the rounding of the float ray / triangle test near the faces. */
+void set_mesh_bounds(const Built& out, uint32_t first, uint32_t count, DMesh& mesh) {
+    BBox all;
+    for (uint32_t i = 0; i < count; ++i) {
+        const DTri& t = out.tris[first + i];
+        float v1[3], v2[3];
+        for (int a = 0; a < 3; ++a) { v1[a] = t.v0[a] + t.e1[a]; v2[a] = t.v0[a] + t.e2[a]; }
+        all.grow(t.v0); all.grow(v1); all.grow(v2);
+    }
+    if (count == 0 || !(all.lo[0] <= all.hi[0])) { /* nothing to hit: an empty box and a sphere no line reaches */
+        for (int a = 0; a < 3; ++a) { mesh.lo[a] = kInf; mesh.hi[a] = -kInf; mesh.bs_c[a] = 0.f; }
+        mesh.bs_r2 = -1.f;
+        return;
+    }
+    float diag = std::sqrt((all.hi[0] - all.lo[0]) * (all.hi[0] - all.lo[0]) + (all.hi[1] - all.lo[1]) * (all.hi[1] - all.lo[1]) +
+                           (all.hi[2] - all.lo[2]) * (all.hi[2] - all.lo[2]));
+    float pad = 1e-4f * diag + 1e-6f;
+    for (int a = 0; a < 3; ++a) { mesh.lo[a] = all.lo[a] - pad; mesh.hi[a] = all.hi[a] + pad; }
+    /* bounding sphere of the padded box, in double, every rounding outward */
+    double c[3], r2 = 0.0;
+    for (int a = 0; a < 3; ++a) { mesh.bs_c[a] = (float)(0.5 * ((double)all.lo[a] + (double)all.hi[a])); c[a] = mesh.bs_c[a]; }
+    for (int a = 0; a < 3; ++a) {
+        double e = std::max(std::fabs((double)all.lo[a] - pad - c[a]), std::fabs((double)all.hi[a] + pad - c[a]));
+        r2 += e * e;
+    }
+    float r2f = (float)(r2 * 1.0001);
+    mesh.bs_r2 = std::isfinite(r2f) ? std::nextafter(r2f, kInf) : kInf;
+}
+
 /* Builds the BVH of the triangles [first, first+count) of out.tris, reorders them into leaf order
  * and returns the root node index (a mesh with one leaf still gets a root node). */
 int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count, DMesh& mesh) {
@@ -231,16 +261,6 @@ int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count, DMesh& mesh) 
     BvhBuilder::Child top = b.build(0, count, 0);
     if (top.leaf) return -1; /* cannot happen for count > 4; the caller then keeps the brute-force loop */
     if (b.max_depth > kBvhMaxDepth) return -2; /* cannot happen either (see the split rule) */
-    for (int a = 0; a < 3; ++a) { mesh.lo[a] = all.lo[a] - pad; mesh.hi[a] = all.hi[a] + pad; }
-    { /* bounding sphere of the padded box, in double, every rounding outward */
-        double c[3], r2 = 0.0;
-        for (int a = 0; a < 3; ++a) { mesh.bs_c[a] = (float)(0.5 * ((double)all.lo[a] + (double)all.hi[a])); c[a] = mesh.bs_c[a]; }
-        for (int a = 0; a < 3; ++a) {
-            double e = std::max(std::fabs((double)all.lo[a] - pad - c[a]), std::fabs((double)all.hi[a] + pad - c[a]));
-            r2 += e * e;
-        }
-        mesh.bs_r2 = std::nextafter((float)(r2 * 1.0001), kInf);
-    }
     /* leaf indices are relative to this mesh: make them global, and permute the triangles */
     std::vector<DTri> sorted(count);
     for (uint32_t i = 0; i < count; ++i) { sorted[i] = out.tris[first + b.order[i]]; out.tri_orig[first + i] = b.order[i]; }
@@ -367,6 +387,7 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
             out.tris.push_back(tr);
             out.tri_orig.push_back(t);
         }
+        set_mesh_bounds(out, o.first_tri, o.n_tris, o);
         if (m.n_triangles > kBvhMinTris) {
             o.bvh_root = build_mesh_bvh(out, o.first_tri, o.n_tris, o);
             if (o.bvh_root < -1) return fail(err, "rt_scene_create: triangle BVH deeper than the traversal stack");
