@@ -69,13 +69,17 @@ RT_DEV f3 norm3_len(f3 a, float& L) {
     float q = a.x * a.x + a.y * a.y + a.z * a.z;
     float lo = fminf(fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
     float hi = fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
-    if (lo >= 0x1p-40f && hi <= 0x1p40f) { /* every component plain => q, L and the quotients are too */
-        L = sqrt_plain(q);
-        float r = rcp_refined(L);
-        return mk3(div_plain(a.x, L, r), div_plain(a.y, L, r), div_plain(a.z, L, r));
+    /* the short sequences run unconditionally (on operands outside the plain range their result is simply
+     * discarded): the common case then crosses no taken branch, which costs a wave more than these 25
+     * instructions; every component plain => q, L and the quotients are too */
+    L = sqrt_plain(q);
+    float r = rcp_refined(L);
+    f3 res = mk3(div_plain(a.x, L, r), div_plain(a.y, L, r), div_plain(a.z, L, r));
+    if (__builtin_expect(!(lo >= 0x1p-40f && hi <= 0x1p40f), 0)) {
+        L = __builtin_sqrtf(q);
+        res = mk3(a.x / L, a.y / L, a.z / L);
     }
-    L = __builtin_sqrtf(q);
-    return mk3(a.x / L, a.y / L, a.z / L);
+    return res;
 }
 RT_DEV f3 norm3(f3 a) { float L; return norm3_len(a, L); }
 /* normalize() of a vector that is already unit length up to rounding (the Ray constructor's second
@@ -90,12 +94,11 @@ RT_DEV f3 norm3(f3 a) { float L; return norm3_len(a, L); }
 RT_DEV f3 norm3_unit(f3 a) {
     float q = a.x * a.x + a.y * a.y + a.z * a.z;
     float lo = fminf(fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
-    if ((uint32_t)(__float_as_int(q) - (0x3f800000 - 4096)) <= 8192u && lo >= 0x1p-40f) {
-        float L = __int_as_float((__float_as_int(q) >> 1) + 0x1fc00000);
-        float r = rcp_refined(L);
-        return mk3(div_plain(a.x, L, r), div_plain(a.y, L, r), div_plain(a.z, L, r));
-    }
-    return norm3(a);
+    float L = __int_as_float((__float_as_int(q) >> 1) + 0x1fc00000);
+    float r = rcp_refined(L);
+    f3 res = mk3(div_plain(a.x, L, r), div_plain(a.y, L, r), div_plain(a.z, L, r));
+    if (__builtin_expect(!((uint32_t)(__float_as_int(q) - (0x3f800000 - 4096)) <= 8192u && lo >= 0x1p-40f), 0)) res = norm3(a);
+    return res;
 }
 RT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 RT_DEV float max_std(float a, float b) { return (a < b) ? b : a; } /* std::max, NaN behaviour included */
