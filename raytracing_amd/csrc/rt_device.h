@@ -545,10 +545,13 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     bool act[RT_SB];
     cnt.rays += RT_SB;
 #pragma unroll
-    for (int j = 0; j < RT_SB; ++j) {
-        float t_in, t_out;
-        act[j] = o_inside || box_test(sc.box_lo, sc.box_hi, o, d[j], t_in, t_out);
-        occ[j] = false;
+    for (int j = 0; j < RT_SB; ++j) { act[j] = true; occ[j] = false; }
+    if (__builtin_expect(!o_inside, 0)) { /* the origin left the root box: the slab test decides, ray by ray */
+#pragma unroll
+        for (int j = 0; j < RT_SB; ++j) {
+            float t_in, t_out;
+            act[j] = box_test(sc.box_lo, sc.box_hi, o, d[j], t_in, t_out);
+        }
     }
     /* tables walked directly with one-ahead record fetches, as in root_closest */
     /* Per object the cheap part runs for all rays of the batch first, in straight-line code, and the rare
