@@ -155,7 +155,7 @@ def main():
             if flop_per_ray <= 0:
                 flop_per_ray = counted
         if flop_per_ray <= 0:
-            flop_per_ray = 499.0  # Cornell 1080p figure counted by the oracle; see DESIGN.md
+            flop_per_ray = 488.97  # what the oracle counts on this frame (include/rt_flops.h constants)
         rays_per_launch = rays_total / args.steps / world  # this rank's kernel ~ 1/world of the frame
         achieved = rays_per_launch * flop_per_ray / (kernel_ms_max * 1e-3) / 1e12
         line = {

@@ -34,7 +34,7 @@ def test_gpu_reproduces_committed_vectors(golden_dir, sid):
     assert hits.tobytes() == g["hits"].tobytes()
     rgb, st = dev.trace(g["t_org"], g["t_dir"], g["t_pixel"], g["t_sample"], seed=1, k0=2)
     assert [st.rays, st.samples, st.nodes] == list(g["t_counts"])
-    assert np.abs(rgb - g["t_rgb"]).max() <= 5e-6          # colours: powf only
+    assert np.abs(rgb - g["t_rgb"]).max() <= 5e-6          # colours differ only through powf (double power rounded once vs glibc)
     img, ist = dev.render(host.camera_default(48, 27), 48, 27, 2, seed=3, tile_w=16, tile_h=8)
     assert [ist.rays, ist.samples, ist.nodes] == list(g["img_counts"])
     assert np.abs(img - g["img"]).max() <= 5e-6

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes (rocpd sqlite) of the render kernel: raw counter sums plus the
-derived figures quoted in DESIGN.md.  usage: pmc_summary.py <dir with p*_results.db> --rays N --ms T"""
+derived figures (instructions per ray, issue utilisation, waits).  usage: pmc_summary.py <dir with p*_results.db> --rays N --ms T"""
 import argparse
 import glob
 import sqlite3
