@@ -9,9 +9,11 @@
 #include "rt_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace rtb {
 
@@ -143,6 +145,12 @@ struct BvhBuilder {
     std::vector<uint32_t> order; /* triangle ids in leaf order */
     float pad;
     int max_depth = 0; /* inner nodes on the longest path */
+    /* When `defer` is set, subtrees of at most `grain` triangles are not built but queued (in left-to-right
+     * order) and their parent gets a placeholder child kDeferred - task: other builders finish them in parallel. */
+    struct Task { uint32_t first, count; int depth; };
+    std::vector<Task>* defer = nullptr;
+    uint32_t grain = 0;
+    static constexpr int32_t kDeferred = -0x40000000;
     BvhBuilder(std::vector<TriInfo>& p, std::vector<DBvhNode>& n, float pad_) : prims(p), nodes(n), pad(pad_) {}
 
     struct Child { bool leaf; int32_t index; int32_t count; BBox box; };
@@ -151,6 +159,10 @@ struct BvhBuilder {
         BBox box, cbox;
         for (uint32_t i = first; i < first + count; ++i) { box.grow(prims[i].box); cbox.grow(prims[i].c); }
         if (count <= 4) return make_leaf(first, count, box);
+        if (defer && count <= grain) {
+            defer->push_back(Task{first, count, depth});
+            return Child{false, kDeferred - (int32_t)(defer->size() - 1), 0, box};
+        }
         int axis = 0;
         float ext[3] = {cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2]};
         if (ext[1] > ext[axis]) axis = 1;
@@ -258,8 +270,50 @@ int32_t build_mesh_bvh(Built& out, uint32_t first, uint32_t count, DMesh& mesh) 
     float pad = 1e-4f * diag + 1e-6f; /* covers the rounding of the float ray / triangle test near box faces */
     int32_t root = (int32_t)out.bvh.size();
     BvhBuilder b(prims, out.bvh, pad);
+    /* Large meshes: the top of the tree is split here, the subtrees below it by a pool of threads, each into
+     * its own node and order arrays (the triangle ranges are disjoint); they are appended afterwards in
+     * left-to-right order and the placeholders in the top nodes patched. */
+    std::vector<BvhBuilder::Task> tasks;
+    unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (count >= 200000 && n_threads > 1) { b.defer = &tasks; b.grain = std::max<uint32_t>(4096, count / (8 * n_threads)); }
     BvhBuilder::Child top = b.build(0, count, 0);
     if (top.leaf) return -1; /* cannot happen for count > 4; the caller then keeps the brute-force loop */
+    if (!tasks.empty()) {
+        struct Sub { std::vector<DBvhNode> nodes; std::vector<uint32_t> order; BvhBuilder::Child top; int max_depth = 0; };
+        std::vector<Sub> subs(tasks.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t t; (t = next.fetch_add(1)) < tasks.size();) {
+                BvhBuilder sb(prims, subs[t].nodes, pad);
+                subs[t].top = sb.build(tasks[t].first, tasks[t].count, tasks[t].depth);
+                subs[t].order.swap(sb.order);
+                subs[t].max_depth = sb.max_depth;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i + 1 < n_threads; ++i) pool.emplace_back(worker);
+        worker();
+        for (std::thread& th : pool) th.join();
+        const size_t top_nodes = out.bvh.size();
+        std::vector<BvhBuilder::Child> done(tasks.size());
+        for (size_t t = 0; t < tasks.size(); ++t) {
+            const int32_t node_base = (int32_t)out.bvh.size(), order_base = (int32_t)b.order.size();
+            for (DBvhNode n : subs[t].nodes) { /* sub-builder indices are relative to its own arrays */
+                if (n.n0 > 0) n.c0 += order_base; else if (n.c0 >= 0) n.c0 += node_base;
+                if (n.n1 > 0) n.c1 += order_base; else if (n.c1 >= 0) n.c1 += node_base;
+                out.bvh.push_back(n);
+            }
+            done[t] = subs[t].top;
+            done[t].index += done[t].leaf ? order_base : node_base;
+            b.order.insert(b.order.end(), subs[t].order.begin(), subs[t].order.end());
+            b.max_depth = std::max(b.max_depth, subs[t].max_depth);
+        }
+        for (size_t k = (size_t)root; k < top_nodes; ++k) {
+            DBvhNode& n = out.bvh[k];
+            if (n.n0 == 0 && n.c0 <= BvhBuilder::kDeferred) { const BvhBuilder::Child& c = done[(size_t)(BvhBuilder::kDeferred - n.c0)]; n.c0 = c.index; n.n0 = c.leaf ? c.count : 0; }
+            if (n.n1 == 0 && n.c1 <= BvhBuilder::kDeferred) { const BvhBuilder::Child& c = done[(size_t)(BvhBuilder::kDeferred - n.c1)]; n.c1 = c.index; n.n1 = c.leaf ? c.count : 0; }
+        }
+    }
     if (b.max_depth > kBvhMaxDepth) return -2; /* cannot happen either (see the split rule) */
     /* leaf indices are relative to this mesh: make them global, and permute the triangles */
     std::vector<DTri> sorted(count);

@@ -100,7 +100,7 @@ def test_builder_under_address_and_ub_sanitizers(tmp_path):
     if gxx is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "build_harness")
-    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-pthread",
            "-I", os.path.join(root, "raytracing_amd", "csrc"), "-I", os.path.join(root, "include"),
            os.path.join(root, "tests", "sanitize", "build_harness.cpp"), os.path.join(root, "raytracing_amd", "csrc", "rt_build.cpp"),
            "-o", exe]
