@@ -109,6 +109,7 @@ int main() {
     { SceneData s; add_objects(s, 2, 5, 1); expect(build_ok(s), "small scene"); ++cases; }
     { SceneData s; add_objects(s, 60, 40, 2); expect(build_ok(s), "kd scene with internal nodes"); ++cases; }
     { SceneData s; add_objects(s, 3, 3, 3); add_grid(s, 96, 0.2f, 4); int d = 0; expect(build_ok(s, &d) && d > 5 && d <= 32, "grid mesh BVH"); ++cases; }
+    { SceneData s; add_objects(s, 2, 2, 21); add_grid(s, 340, 0.3f, 22); int d = 0; expect(build_ok(s, &d) && d <= 32, "230k triangles: subtrees built by the thread pool"); ++cases; }
     { SceneData s; add_objects(s, 1, 1, 5); add_grid(s, 40, 0.f, 6); add_grid(s, 5, 0.1f, 7); expect(build_ok(s), "two meshes, one flat, one small"); ++cases; }
     { /* every triangle the same: centroids coincide */
         SceneData s; add_objects(s, 1, 1, 8);
