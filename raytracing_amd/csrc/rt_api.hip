@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
         float u = ((float)(int)x + 0.5f) / (float)(int)rp.w;
         float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
         f3 o, d;
-        primary_ray(cam, u, v, &o, &d);
+        primary_ray(*cam, u, v, o, d);
         Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
         Rng rng; rng.key = 0; rng.k = 0;
         (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene
             float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
-            primary_ray(cam, u, v, &o, &d);
+            primary_ray(*cam, u, v, o, d);
             col = trace_path<M>(sc, o, norm3_unit(d), rng, cnt);
             ++my_samples;
         }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene
                 float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
                 float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
                 f3 o, d;
-                primary_ray(cam, u, v, &o, &d);
+                primary_ray(*cam, u, v, o, d);
                 col = trace_path<M>(sc, o, norm3_unit(d), rng, cnt); /* Ray(pos, dir) normalises again */
                 ++my_samples;
             }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __re
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 o, d;
-    primary_ray_inl(cam, u[i], v[i], o, d);
+    primary_ray(cam, u[i], v[i], o, d);
     org[3 * i] = o.x; org[3 * i + 1] = o.y; org[3 * i + 2] = o.z;
     dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
 }

@@ -845,7 +845,7 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
 
 /* ---- screen_space_to_world_space_ray, R/src/matrixUtilities.h:198-222 --------------------
  * double arithmetic exactly as the reference; the direction comes back normalised once. */
-RT_DEV void primary_ray_inl(const DCamera& cam, float u, float v, f3& o, f3& d) {
+RT_DEV void primary_ray(const DCamera& cam, float u, float v, f3& o, f3& d) {
     double x = (double)2.f * (double)u - (double)1.f;
     double y = -((double)2.f * (double)v - (double)1.f);
     double z = cam.depth_near, w = 1.0;
@@ -862,12 +862,6 @@ RT_DEV void primary_ray_inl(const DCamera& cam, float u, float v, f3& o, f3& d) 
     f3 world = mk3((float)(b0 / b3), (float)(b1 / b3), (float)(b2 / b3));
     o = ld3(cam.eye);
     d = norm3(world - o);
-}
-
-/* out-of-line form for the render kernel: keeps the 2 x 16 doubles out of the registers that stay
- * live while the path is traced */
-__device__ __attribute__((noinline)) void primary_ray(const DCamera* cam, float u, float v, f3* o, f3* d) {
-    primary_ray_inl(*cam, u, v, *o, *d);
 }
 
 #endif /* RT_DEVICE_H */
