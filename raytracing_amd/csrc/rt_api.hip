@@ -1,7 +1,8 @@
 /*
  * rt_api.hip -- HIP kernels and the C-ABI entry points of include/rtamd.h.
  *
- * Kernels (all in rt_device.h terms, gfx950, 256-thread workgroups = 4 waves):
+ * Kernels (all in rt_device.h terms, gfx950; 256-thread workgroups except k_render, which runs one wave per
+ * workgroup):
  *   k_render         one WAVE per pixel, one lane per sample of a 64-sample chunk; each lane traces
  *                    its whole path tree; the wave then adds its lanes' colours in sample order
  *                    (the reference's float summation order, R/main.cpp:185-193) and lane 0
@@ -65,6 +66,12 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     }
 }
 
+#ifndef RT_RENDER_WAVES
+/* Waves (pixels) per workgroup of the render kernel.  One: a workgroup holds its wave slots until its slowest
+ * wave is done, and next to a glass-rim pixel that takes 3 ms the three neighbours' slots would sit idle
+ * (measured: 27.7 -> 27.2 ms on the full frame, 3.74 -> 3.61 ms on the slowest of eight ranks). */
+#define RT_RENDER_WAVES 1
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4 /* waves per SIMD the render variants are compiled for (<= 128 VGPRs) */
 #endif
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
         float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
         f3 o, d;
         primary_ray(*cam, u, v, o, d);
-        Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
+        Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
         Rng rng; rng.key = 0; rng.k = 0;
         (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
         deepest = max(deepest, cnt.nodes);
@@ -147,10 +154,10 @@ extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
  * PACK = true : spp <= 32, 64 / spp pixels per wave, lane = (pixel, sample), so that few samples
  *               per pixel do not leave most lanes idle. */
 template <int M, bool PACK>
-__global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
+__global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters, const uint32_t* __restrict__ order) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t wave = blockIdx.x * (uint32_t)RT_RENDER_WAVES + (threadIdx.x >> 6);
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
     const uint32_t px_per_wave = PACK ? 64u / rp.spp : 1u;
     const uint32_t waves_per_tile = PACK ? (px_per_tile + px_per_wave - 1) / px_per_wave : px_per_tile;
@@ -168,8 +175,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene
     const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
     const bool in_image = has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
-    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
+    __shared__ uint32_t s_stack[RT_STACK_LDS * 64 * RT_RENDER_WAVES];
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = 64 * RT_RENDER_WAVES;
     uint32_t my_samples = 0;
     f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane of a pixel */
     if (in_image && rp.sample0 > 0) acc = ld3(dst);
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* 
     if (i >= n) return;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
     HitRec rec = closest_rec<M>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
     int tri = (h.hit && h.type == RT_MESH) ? (int)ldc(&sc.tri_orig[h.tri]) : -1;
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     const DMesh m = ldc(&sc.meshes[mesh]);
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
     if (mesh_closest<RT_M_BVH>(sc, m, o, d, cnt, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
     FullHit h = finish_hit(sc, rec, o, d);
     out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)ldc(&sc.tri_orig[h.tri]) : -1, rec.u, rec.v);
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __re
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x;
+    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
     uint32_t smp = 0;
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
@@ -368,7 +375,7 @@ namespace {
     } while (0)
 
 #define RT_RENDER_CASE(m, p, grid, stream, ...) \
-    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0>), grid, dim3(256), 0, stream, __VA_ARGS__); break;
+    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break;
 #define RT_DISPATCH_RENDER(mode, pack, grid, stream, ...)                                              \
     do {                                                                                               \
         switch (((mode) & 3) * 2 + ((pack) ? 1 : 0)) {                                                 \
@@ -472,7 +479,7 @@ int make_render_params(uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint
     rp.n_local_tiles = (uint32_t)rt_tiles_per_rank(w, h, tile_w, tile_h, rank, world);
     rp.sample0 = 0; rp.spp_total = spp; rp.pad[0] = rp.pad[1] = rp.pad[2] = 0;
     uint64_t waves = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
-    if (waves / 4 + 1 > 0x7fffffffull) return fail(RT_E_LIMIT, "rt_render: grid too large");
+    if (waves / RT_RENDER_WAVES + 1 > 0x7fffffffull) return fail(RT_E_LIMIT, "rt_render: grid too large");
     return RT_OK;
 }
 
@@ -833,7 +840,7 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
         const uint32_t px_per_wave = pack ? 64u / n : 1u;
         const uint64_t waves = (uint64_t)rp.n_local_tiles * (((uint64_t)tile_w * tile_h + px_per_wave - 1) / px_per_wave);
         rp.spp = n; rp.sample0 = s0;
-        dim3 grid((unsigned)((waves + 3) / 4));
+        dim3 grid((unsigned)((waves + RT_RENDER_WAVES - 1) / RT_RENDER_WAVES));
         RT_DISPATCH_RENDER(r->mode, pack, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order);
         HIP_TRY(hipGetLastError());
         s0 += n; left -= n;

@@ -121,14 +121,15 @@ RT_DEV T ldc(const T* p) {
 }
 
 /* per-lane context: work counters (summed per workgroup at the end) and the base of this lane's
- * slice of the LDS traversal stack (element i lives at stack[i * RT_STACK_STRIDE]) */
-struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris; /* BVH nodes fetched, triangles tested */ };
+ * slice of the LDS traversal stack (element i lives at stack[i * stack_stride]) */
+struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris; /* BVH nodes fetched, triangles tested */
+             uint32_t stack_stride; /* threads of the workgroup: element i of the lane's stack lives at stack[i * stack_stride] */ };
 /* kernel variants: bit 0 = the object kd-tree has internal nodes, bit 1 = some mesh has a triangle BVH.
  * Code a scene cannot reach is compiled out of its variant, which keeps the common variant's registers low. */
 #define RT_M_KD 1
 #define RT_M_BVH 2
 #define RT_STACK_LDS 32      /* entries per lane, all in LDS: the host bounds the BVH depth to this (kBvhMaxDepth) */
-#define RT_STACK_STRIDE 256  /* workgroup size: lane-interleaved, conflict-free LDS layout */
+#define RT_STACK_STRIDE 256  /* workgroup size of the lane-per-ray kernels: lane-interleaved, conflict-free LDS layout */
 
 /* closest hit so far: enough to rebuild position and normal of the winner afterwards */
 struct HitRec {
@@ -280,8 +281,8 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
     bool found = false;
     uint32_t best_orig = 0xffffffffu;
     int cur = m.bvh_root;
-    auto push = [&](int e) { cnt.stack[(sp++ & (RT_STACK_LDS - 1)) * RT_STACK_STRIDE] = (uint32_t)e; }; /* never wraps: depth <= RT_STACK_LDS */
-    auto pop = [&]() -> int { return (int)cnt.stack[(--sp & (RT_STACK_LDS - 1)) * RT_STACK_STRIDE]; };
+    auto push = [&](int e) { cnt.stack[(sp++ & (RT_STACK_LDS - 1)) * cnt.stack_stride] = (uint32_t)e; }; /* never wraps: depth <= RT_STACK_LDS */
+    auto pop = [&]() -> int { return (int)cnt.stack[(--sp & (RT_STACK_LDS - 1)) * cnt.stack_stride]; };
     for (;;) {
         bool done = false;
         while (cur >= 0) { /* inner nodes */
