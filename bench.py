@@ -30,9 +30,9 @@ if ROOT not in sys.path:
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X spec: 256 CU x 4 SIMD x 16 lanes x 2 (packed) x 2 (FMA) x 2.4 GHz
 # Memory-side traffic of one k_render launch of the default workload, bytes: rocprofv3 FETCH_SIZE + WRITE_SIZE of this
-# build (profiles/r1_g_traffic.txt; counters cannot be read from inside the process).  Almost all of it is register-spill
+# build (profiles/r1_h_traffic.txt; counters cannot be read from inside the process).  Almost all of it is register-spill
 # and path-frame traffic to scratch memory that stays in the Infinity Cache; the image itself is 25 MB.
-MEASURED_TRAFFIC_BYTES_1080P_64SPP = 12.44e9
+MEASURED_TRAFFIC_BYTES_1080P_64SPP = 11.81e9
 
 
 def cpu_baseline(w, h, spp, seed, threads=1):
@@ -180,7 +180,7 @@ def main():
                          "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4),
                          "traffic": (MEASURED_TRAFFIC_BYTES_1080P_64SPP / world
                                      if (w, h, spp) == (1920, 1080, 64) else None),
-                         "traffic_note": "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r1_g_traffic.txt (scratch, "
+                         "traffic_note": "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r1_h_traffic.txt (scratch, "
                                          "Infinity-Cache resident); algorithmic output 12 B per pixel",
                          "kernel": "k_render", "kernel_ms": round(kernel_ms_max, 3), "flop_per_ray": round(flop_per_ray, 2),
                          "kernel_mrays_per_s": round(rays_per_launch / (kernel_ms_max * 1e-3) / 1e6, 2)},
