@@ -196,6 +196,16 @@ int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches);
 int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out);
 int rt_scene_destroy(rt_scene_t scene);
 
+/* rt_scene_create with options.  RT_BUILD_BVH_DEVICE: the per-mesh triangle BVHs are built on the GPU from
+ * the uploaded triangle records (Morton order, top-down cuts; milliseconds for millions of triangles) instead
+ * of by the host's binned-SAH builder (a better tree, seconds for 10 M triangles).  Hit records do not depend
+ * on the choice: the reference's Mesh::intersect is a loop over all triangles (R/src/Mesh.h:225), both trees
+ * only have to reach every triangle it would accept.  rt_scene_create(desc, out) is
+ * rt_scene_create_ex(desc, 0, out), or with RT_BUILD_BVH_DEVICE when the environment has
+ * RTAMD_BVH_BUILD=device. */
+#define RT_BUILD_BVH_DEVICE 1u
+int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* out);
+
 /* Host-only dry run of rt_scene_create (needs neither rt_init nor a GPU): validates the description, builds
  * the object kd-tree and the triangle BVHs, checks the BVHs (every triangle in exactly one leaf, boxes nested
  * and enclosing their triangles, depth within the device's traversal stack) and reports what was built. */
@@ -207,6 +217,16 @@ typedef struct rt_build_info {
     uint64_t device_bytes;            /* size of the scene tables in HBM */
 } rt_build_info;
 int rt_scene_check(const rt_scene_desc* desc, rt_build_info* info);
+
+/* The same checks on a scene that exists: copies the triangle and node tables back from the device and
+ * verifies them (so it also covers BVHs built on the GPU).  info / times may be NULL.  times: what
+ * rt_scene_create spent -- host_ms: host preparation (records, kd-tree, host BVH build if any);
+ * device_sort_ms / device_tree_ms: device time of the GPU BVH build (keys + sort + permutation, hierarchy +
+ * boxes; 0 for a host build); total_ms: the whole call including uploads. */
+typedef struct rt_build_times {
+    double host_ms, device_sort_ms, device_tree_ms, total_ms;
+} rt_build_times;
+int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times);
 
 /* Flattened object kd-tree, for inspection / parity tests.  nodes: 8 int32 per node
  * {is_leaf, axis, cut(float bits), left, right, first_ref, n_refs, depth}; refs: 2 int32 per

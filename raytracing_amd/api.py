@@ -68,12 +68,18 @@ class BuildInfo(C.Structure):
                 ("bvh_max_depth", C.c_uint32), ("kernel_variant", C.c_uint32), ("device_bytes", C.c_uint64)]
 
 
+class BuildTimes(C.Structure):
+    _fields_ = [("host_ms", C.c_double), ("device_sort_ms", C.c_double), ("device_tree_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+BUILD_BVH_DEVICE = 1
+
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri", "<i4"), ("t", "<f4"),
                       ("u", "<f4"), ("v", "<f4"), ("pad0", "<f4"), ("p", "<f4", 3), ("pad1", "<f4"),
                       ("n", "<f4", 3), ("pad2", "<f4")])
 
 # every symbol include/rtamd.h declares
-EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_destroy", "rt_scene_kdtree",
+EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
            "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
@@ -93,6 +99,8 @@ def lib():
         L.rt_init.argtypes = [C.c_int]
         L.rt_scene_check.argtypes = [C.POINTER(SceneDesc), C.POINTER(BuildInfo)]
         L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(u64)]
+        L.rt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), u32, C.POINTER(u64)]
+        L.rt_scene_verify.argtypes = [u64, C.POINTER(BuildInfo), C.POINTER(BuildTimes)]
         L.rt_scene_destroy.argtypes = [u64]
         L.rt_scene_kdtree.argtypes = [u64, vp, C.POINTER(u32), vp, C.POINTER(u32), vp]
         L.rt_intersect.argtypes = [u64, vp, vp, C.c_size_t, vp]
@@ -146,12 +154,22 @@ def copy_struct(dst_type, src):
 class DeviceScene:
     """A scene uploaded with rt_scene_create."""
 
-    def __init__(self, desc, keep=None):
+    def __init__(self, desc, keep=None, flags=None):
+        """flags: None = rt_scene_create (host BVH build unless RTAMD_BVH_BUILD=device), else rt_scene_create_ex."""
         h = C.c_uint64()
         d = desc if isinstance(desc, SceneDesc) else copy_struct(SceneDesc, desc)
-        check(lib().rt_scene_create(C.byref(d), C.byref(h)))
+        if flags is None:
+            check(lib().rt_scene_create(C.byref(d), C.byref(h)))
+        else:
+            check(lib().rt_scene_create_ex(C.byref(d), flags, C.byref(h)))
         self.h = h.value
         self._keep = keep
+
+    def verify(self):
+        """rt_scene_verify: reads the device tables back and checks the BVHs; returns (BuildInfo, BuildTimes)."""
+        info, times = BuildInfo(), BuildTimes()
+        check(lib().rt_scene_verify(self.h, C.byref(info), C.byref(times)))
+        return info, times
 
     def close(self):
         if self.h:

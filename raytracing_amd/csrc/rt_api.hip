@@ -17,6 +17,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "rt_build.h"
+#include "rt_bvh_device.h"
 #include "rt_device.h"
 
 /* ======================================================================================== */
@@ -391,6 +393,9 @@ struct SceneRes {
     DeviceScene dev{};
     int mode = 0;
     bool has_bounce = false; /* some sphere is a mirror or glass: only then do path trees differ in depth */
+    size_t n_tris = 0, n_bvh = 0, n_normals = 0; /* lengths of the device tables (their host copies are dropped) */
+    int bvh_depth = 0;
+    rt_build_times times{};
     std::vector<void*> allocs;
 };
 
@@ -572,41 +577,174 @@ int rt_scene_check(const rt_scene_desc* desc, rt_build_info* info) {
     return RT_OK;
 }
 
-int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
+int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* out) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_scene_create: call rt_init first");
     if (!desc || !out) return fail(RT_E_INVALID, "rt_scene_create: null argument");
+    if (flags & ~(uint32_t)RT_BUILD_BVH_DEVICE) return fail(RT_E_INVALID, "rt_scene_create_ex: unknown flag");
     HIP_TRY(hipSetDevice(g.device));
+    const bool device_bvh = (flags & RT_BUILD_BVH_DEVICE) != 0;
+    const auto t0 = std::chrono::steady_clock::now();
     SceneRes* r = new SceneRes();
     std::string err;
-    if (!rtb::build_scene(*desc, r->host, err)) { delete r; return fail(RT_E_INVALID, err); }
+    if (!rtb::build_scene(*desc, r->host, err, device_bvh)) { delete r; return fail(RT_E_INVALID, err); }
     int max_depth = 0;
     for (const DKdNode& k : r->host.kd) max_depth = k.depth > max_depth ? k.depth : max_depth;
     if (max_depth >= RT_KD_MAX_DEPTH) { delete r; return fail(RT_E_LIMIT, "rt_scene_create: kd-tree deeper than 15 levels"); }
+    r->times.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     DeviceScene& d = r->dev;
     int rc;
     if ((rc = upload(r, r->host.spheres, &d.spheres)) || (rc = upload(r, r->host.squares, &d.squares)) ||
-        (rc = upload(r, r->host.meshes, &d.meshes)) || (rc = upload(r, r->host.tris, &d.tris)) ||
-        (rc = upload(r, r->host.tri_orig, &d.tri_orig)) || (rc = upload(r, r->host.bvh, &d.bvh)) ||
+        (rc = upload(r, r->host.tris, &d.tris)) || (rc = upload(r, r->host.tri_orig, &d.tri_orig)) ||
+        (rc = upload(r, r->host.bvh, &d.bvh)) ||
         (rc = upload(r, r->host.normals, &d.normals)) || (rc = upload(r, r->host.materials, &d.materials)) ||
         (rc = upload(r, r->host.lights, &d.lights)) || (rc = upload(r, r->host.kd, &d.kd)) ||
         (rc = upload(r, r->host.refs, &d.refs))) {
         release(r);
         return rc;
     }
+    r->n_tris = r->host.tris.size();
+    r->n_normals = r->host.normals.size();
+    r->n_bvh = r->host.bvh.size();
+    std::vector<uint32_t> bvh_todo; /* device path: meshes that get a BVH, and the pad of their node boxes */
+    std::vector<float> bvh_pad;
+    if (device_bvh && !r->host.meshes.empty()) {
+        /* triangle records, mesh bounds and BVHs are made on the device from the caller's raw pools */
+        const size_t n_mesh = r->host.meshes.size();
+        uint64_t total = 0;
+        for (const DMesh& m : r->host.meshes) total += m.n_tris;
+        Scratch tmp;
+        float* d_pos; uint32_t* d_idx; uint32_t* d_box; float* d_nrm = nullptr; DTri* d_tris = nullptr; uint32_t* d_orig = nullptr;
+        hipError_t e = hipSuccess;
+        if ((rc = tmp.get((void**)&d_pos, (size_t)desc->n_vertices * 12)) || (rc = tmp.get((void**)&d_idx, (size_t)desc->n_triangles * 12)) ||
+            (rc = tmp.get((void**)&d_box, n_mesh * 32))) { release(r); return rc; }
+        if (desc->n_vertices) {
+            e = hipMalloc((void**)&d_nrm, (size_t)desc->n_vertices * 12);
+            if (e == hipSuccess) r->allocs.push_back(d_nrm);
+        }
+        if (e == hipSuccess && total) { e = hipMalloc((void**)&d_tris, (size_t)total * sizeof(DTri)); if (e == hipSuccess) r->allocs.push_back(d_tris); }
+        if (e == hipSuccess && total) { e = hipMalloc((void**)&d_orig, (size_t)total * 4); if (e == hipSuccess) r->allocs.push_back(d_orig); }
+        std::vector<uint32_t> boxes(n_mesh * 8);
+        for (size_t k = 0; k < n_mesh; ++k) rtd::box_init(&boxes[8 * k]);
+        if (e == hipSuccess && desc->n_vertices) e = hipMemcpyAsync(d_pos, desc->positions, (size_t)desc->n_vertices * 12, hipMemcpyHostToDevice, g.stream);
+        if (e == hipSuccess && desc->n_vertices) e = hipMemcpyAsync(d_nrm, desc->normals, (size_t)desc->n_vertices * 12, hipMemcpyHostToDevice, g.stream);
+        if (e == hipSuccess && desc->n_triangles) e = hipMemcpyAsync(d_idx, desc->triangles, (size_t)desc->n_triangles * 12, hipMemcpyHostToDevice, g.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_box, boxes.data(), n_mesh * 32, hipMemcpyHostToDevice, g.stream);
+        for (size_t k = 0; k < n_mesh && e == hipSuccess; ++k) {
+            const rt_mesh& m = desc->meshes[k];
+            const DMesh& o = r->host.meshes[k];
+            e = rtd::make_mesh_tris(d_pos + 3 * (size_t)m.first_vertex, d_idx + 3 * (size_t)m.first_triangle, m.first_vertex, m.n_vertices, m.n_triangles,
+                                    d_tris + o.first_tri, d_orig + o.first_tri, d_box + 8 * k, g.stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(boxes.data(), d_box, n_mesh * 32, hipMemcpyDeviceToHost, g.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        if (e != hipSuccess) { release(r); return fail(RT_E_HIP, std::string("rt_scene_create: triangle records: ") + hipGetErrorString(e)); }
+        for (size_t k = 0; k < n_mesh; ++k) {
+            float lo[3], hi[3];
+            bool bad = false;
+            rtd::box_decode(&boxes[8 * k], lo, hi, bad);
+            if (bad) { release(r); return fail(RT_E_INVALID, "rt_scene_create: triangle vertex index out of range"); }
+            DMesh& o = r->host.meshes[k];
+            const float pad = rtb::mesh_bounds_from_box(lo, hi, o.n_tris, o);
+            if (o.n_tris > rtb::kBvhMinTris) { bvh_todo.push_back((uint32_t)k); bvh_pad.push_back(pad); }
+        }
+        d.tris = d_tris; d.tri_orig = d_orig; d.normals = d_nrm;
+        r->n_tris = (size_t)total;
+        r->n_normals = 3 * (size_t)desc->n_vertices;
+    }
+    if (!bvh_todo.empty()) { /* the triangle BVHs are built here, from the records on the device */
+        std::vector<rtd::DeviceBvh> parts;
+        int32_t base = 0;
+        hipError_t e = hipSuccess;
+        for (size_t k = 0; k < bvh_todo.size() && e == hipSuccess; ++k) {
+            DMesh& m = r->host.meshes[bvh_todo[k]];
+            rtd::DeviceBvh b;
+            e = rtd::build_mesh_bvh(const_cast<DTri*>(d.tris), const_cast<uint32_t*>(d.tri_orig), m.first_tri, m.n_tris, m.lo, m.hi,
+                                    bvh_pad[k], base, rtb::kBvhMaxDepth, g.stream, b, err);
+            if (e != hipSuccess) break;
+            m.bvh_root = b.root;
+            base += (int32_t)b.n_nodes;
+            r->times.device_sort_ms += b.sort_ms; r->times.device_tree_ms += b.tree_ms;
+            r->bvh_depth = b.max_depth > r->bvh_depth ? b.max_depth : r->bvh_depth;
+            parts.push_back(b);
+        }
+        DBvhNode* all = nullptr;
+        if (e == hipSuccess && parts.size() == 1) {
+            all = parts[0].nodes; parts.clear();
+        } else if (e == hipSuccess) {
+            e = hipMalloc((void**)&all, (size_t)base * sizeof(DBvhNode));
+            size_t at = 0;
+            for (size_t k = 0; k < parts.size() && e == hipSuccess; ++k) {
+                e = hipMemcpy(all + at, parts[k].nodes, (size_t)parts[k].n_nodes * sizeof(DBvhNode), hipMemcpyDeviceToDevice);
+                at += parts[k].n_nodes;
+            }
+            if (e != hipSuccess && all) { (void)hipFree(all); all = nullptr; }
+            if (e != hipSuccess) err = std::string("rt_scene_create: node table: ") + hipGetErrorString(e);
+        }
+        for (rtd::DeviceBvh& b : parts) (void)hipFree(b.nodes);
+        if (e != hipSuccess) { release(r); return fail(e == hipErrorInvalidValue ? RT_E_LIMIT : RT_E_HIP, err); }
+        r->allocs.push_back(all);
+        d.bvh = all;
+        r->n_bvh = (size_t)base;
+    }
+    if ((rc = upload(r, r->host.meshes, &d.meshes))) { release(r); return rc; }
     d.n_spheres = (uint32_t)r->host.spheres.size(); d.n_squares = (uint32_t)r->host.squares.size();
     d.n_meshes = (uint32_t)r->host.meshes.size(); d.n_lights = (uint32_t)r->host.lights.size();
     d.n_kd = (uint32_t)r->host.kd.size(); d.n_refs = (uint32_t)r->host.refs.size();
     for (int a = 0; a < 3; ++a) { d.box_lo[a] = r->host.box_lo[a]; d.box_hi[a] = r->host.box_hi[a]; }
     d.kd_epsilon = r->host.kd_epsilon;
     d.root_is_leaf = (!r->host.kd.empty() && r->host.kd[0].leaf) ? 1 : 0;
-    r->mode = (d.root_is_leaf ? 0 : RT_M_KD) | (r->host.bvh.empty() ? 0 : RT_M_BVH);
+    r->mode = (d.root_is_leaf ? 0 : RT_M_KD) | (r->n_bvh ? RT_M_BVH : 0);
     for (const DSphere& sp : r->host.spheres) {
         const int mt = r->host.materials[(size_t)sp.mat].type;
         r->has_bounce = r->has_bounce || mt == RT_MAT_MIRROR || mt == RT_MAT_GLASS;
     }
+    /* the big tables now live on the device only (rt_scene_verify reads them back) */
+    std::vector<DTri>().swap(r->host.tris);
+    std::vector<uint32_t>().swap(r->host.tri_orig);
+    std::vector<DBvhNode>().swap(r->host.bvh);
+    std::vector<float>().swap(r->host.normals);
+    r->times.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     rt_scene_t h = g.next_handle++;
     g.scenes[h] = r;
     *out = h;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
+    const char* b = std::getenv("RTAMD_BVH_BUILD");
+    return rt_scene_create_ex(desc, (b && std::strcmp(b, "device") == 0) ? (uint32_t)RT_BUILD_BVH_DEVICE : 0u, out);
+}
+
+int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times) {
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_scene_verify: unknown scene");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    rtb::Built b; /* the tables the kernels read, copied back */
+    b.meshes = r->host.meshes;
+    b.tris.resize(r->n_tris); b.tri_orig.resize(r->n_tris); b.bvh.resize(r->n_bvh);
+    if (r->n_tris) {
+        HIP_TRY(hipMemcpy(b.tris.data(), r->dev.tris, r->n_tris * sizeof(DTri), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.tri_orig.data(), r->dev.tri_orig, r->n_tris * 4, hipMemcpyDeviceToHost));
+    }
+    if (r->n_bvh) HIP_TRY(hipMemcpy(b.bvh.data(), r->dev.bvh, r->n_bvh * sizeof(DBvhNode), hipMemcpyDeviceToHost));
+    int depth = 0;
+    std::string err;
+    if (!rtb::verify_bvh(b, depth, err)) return fail(RT_E_LIMIT, err);
+    if (info) {
+        std::memset(info, 0, sizeof(*info));
+        int kd_depth = 0;
+        for (const DKdNode& k : r->host.kd) kd_depth = k.depth > kd_depth ? k.depth : kd_depth;
+        info->kd_nodes = (uint32_t)r->host.kd.size(); info->kd_max_depth = (uint32_t)kd_depth;
+        for (const DMesh& m : b.meshes) info->bvh_meshes += m.bvh_root >= 0 ? 1u : 0u;
+        info->bvh_nodes = (uint32_t)r->n_bvh; info->bvh_max_depth = (uint32_t)depth;
+        info->kernel_variant = (uint32_t)r->mode;
+        info->device_bytes = r->host.spheres.size() * sizeof(DSphere) + r->host.squares.size() * sizeof(DSquare) + b.meshes.size() * sizeof(DMesh) +
+                             r->n_tris * (sizeof(DTri) + 4) + r->n_bvh * sizeof(DBvhNode) + (size_t)r->n_normals * 4 +
+                             r->host.materials.size() * sizeof(DMaterial) + r->host.lights.size() * sizeof(DLight) +
+                             r->host.kd.size() * sizeof(DKdNode) + r->host.refs.size() * sizeof(DRef);
+    }
+    if (times) *times = r->times;
     return RT_OK;
 }
 

@@ -221,8 +221,9 @@ struct BvhBuilder {
 };
 
 /* Padded box and bounding sphere of a mesh's (scaled) triangles: what a ray has to come near before any of its
- * triangles can report a hit.  The pad covers the rounding of the float ray / triangle test near the faces. */
-void set_mesh_bounds(const Built& out, uint32_t first, uint32_t count, DMesh& mesh) {
+ * triangles can report a hit.  The pad covers the rounding of the float ray / triangle test near the faces;
+ * it is returned because the node boxes of the mesh's BVH take the same one. */
+float set_mesh_bounds(const Built& out, uint32_t first, uint32_t count, DMesh& mesh) {
     BBox all;
     for (uint32_t i = 0; i < count; ++i) {
         const DTri& t = out.tris[first + i];
@@ -230,25 +231,33 @@ void set_mesh_bounds(const Built& out, uint32_t first, uint32_t count, DMesh& me
         for (int a = 0; a < 3; ++a) { v1[a] = t.v0[a] + t.e1[a]; v2[a] = t.v0[a] + t.e2[a]; }
         all.grow(t.v0); all.grow(v1); all.grow(v2);
     }
-    if (count == 0 || !(all.lo[0] <= all.hi[0])) { /* nothing to hit: an empty box and a sphere no line reaches */
+    return mesh_bounds_from_box(all.lo, all.hi, count, mesh);
+}
+
+}  // namespace
+
+float mesh_bounds_from_box(const float lo[3], const float hi[3], uint32_t count, DMesh& mesh) {
+    if (count == 0 || !(lo[0] <= hi[0])) { /* nothing to hit: an empty box and a sphere no line reaches */
         for (int a = 0; a < 3; ++a) { mesh.lo[a] = kInf; mesh.hi[a] = -kInf; mesh.bs_c[a] = 0.f; }
         mesh.bs_r2 = -1.f;
-        return;
+        return 0.f;
     }
-    float diag = std::sqrt((all.hi[0] - all.lo[0]) * (all.hi[0] - all.lo[0]) + (all.hi[1] - all.lo[1]) * (all.hi[1] - all.lo[1]) +
-                           (all.hi[2] - all.lo[2]) * (all.hi[2] - all.lo[2]));
+    float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
     float pad = 1e-4f * diag + 1e-6f;
-    for (int a = 0; a < 3; ++a) { mesh.lo[a] = all.lo[a] - pad; mesh.hi[a] = all.hi[a] + pad; }
+    for (int a = 0; a < 3; ++a) { mesh.lo[a] = lo[a] - pad; mesh.hi[a] = hi[a] + pad; }
     /* bounding sphere of the padded box, in double, every rounding outward */
     double c[3], r2 = 0.0;
-    for (int a = 0; a < 3; ++a) { mesh.bs_c[a] = (float)(0.5 * ((double)all.lo[a] + (double)all.hi[a])); c[a] = mesh.bs_c[a]; }
+    for (int a = 0; a < 3; ++a) { mesh.bs_c[a] = (float)(0.5 * ((double)lo[a] + (double)hi[a])); c[a] = mesh.bs_c[a]; }
     for (int a = 0; a < 3; ++a) {
-        double e = std::max(std::fabs((double)all.lo[a] - pad - c[a]), std::fabs((double)all.hi[a] + pad - c[a]));
+        double e = std::max(std::fabs((double)lo[a] - pad - c[a]), std::fabs((double)hi[a] + pad - c[a]));
         r2 += e * e;
     }
     float r2f = (float)(r2 * 1.0001);
     mesh.bs_r2 = std::isfinite(r2f) ? std::nextafter(r2f, kInf) : kInf;
+    return pad;
 }
+
+namespace {
 
 /* Builds the BVH of the triangles [first, first+count) of out.tris, reorders them into leaf order
  * and returns the root node index (a mesh with one leaf still gets a root node). */
@@ -382,7 +391,7 @@ bool verify_bvh(const Built& b, int& max_depth, std::string& err) {
     return true;
 }
 
-bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
+bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defer_meshes) {
     out = Built();
     if ((d.n_spheres && !d.spheres) || (d.n_squares && !d.squares) || (d.n_meshes && !d.meshes) ||
         (d.n_lights && !d.lights) || (d.n_materials && !d.materials))
@@ -422,13 +431,21 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
         out.squares.push_back(o);
     }
     const float scaling = 1.000001f;  /* R/src/Mesh.h:220 */
+    uint64_t deferred_tris = 0;
     for (uint32_t i = 0; i < d.n_meshes; ++i) {
         const rt_mesh& m = d.meshes[i];
         if (!mat_ok(m.material)) return fail(err, "rt_scene_create: mesh material index out of range");
         if ((uint64_t)m.first_vertex + m.n_vertices > d.n_vertices || (uint64_t)m.first_triangle + m.n_triangles > d.n_triangles)
             return fail(err, "rt_scene_create: mesh slice outside the vertex / triangle pools");
         DMesh o{};
-        o.first_tri = (uint32_t)out.tris.size(); o.n_tris = m.n_triangles; o.mat = m.material; o.bvh_root = -1;
+        o.mat = m.material; o.bvh_root = -1; o.n_tris = m.n_triangles;
+        if (defer_meshes) { /* records, bounds and BVH are made on the device from the caller's arrays */
+            o.first_tri = (uint32_t)deferred_tris;
+            deferred_tris += m.n_triangles;
+            out.meshes.push_back(o);
+            continue;
+        }
+        o.first_tri = (uint32_t)out.tris.size();
         for (uint32_t t = 0; t < m.n_triangles; ++t) {
             const uint32_t* idx = d.triangles + 3 * ((size_t)m.first_triangle + t);
             if (idx[0] >= m.n_vertices || idx[1] >= m.n_vertices || idx[2] >= m.n_vertices)
@@ -448,7 +465,8 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err) {
         }
         out.meshes.push_back(o);
     }
-    out.normals.assign(d.normals, d.normals + 3 * (size_t)d.n_vertices);
+    if (deferred_tris > 0xffffffffull) return fail(err, "rt_scene_create: more than 2^32 triangles");
+    if (!defer_meshes) out.normals.assign(d.normals, d.normals + 3 * (size_t)d.n_vertices);
     for (uint32_t i = 0; i < d.n_lights; ++i) {
         const rt_light& l = d.lights[i];
         DLight o{};

@@ -29,7 +29,12 @@ struct Built {
 /* meshes with more than kBvhMinTris triangles get a BVH; smaller ones keep the reference's loop */
 const uint32_t kBvhMinTris = 64;
 const int kBvhMaxDepth = 32; /* inner nodes on any root-to-leaf path = entries of the device's traversal stack */
-bool build_scene(const rt_scene_desc& d, Built& out, std::string& err);
+/* defer_meshes: everything per triangle is left to the caller (the device path, rt_bvh_device.hip): meshes come
+ * back with first_tri / n_tris / mat only, and tris, tri_orig, bvh and normals stay empty. */
+bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defer_meshes = false);
+/* Padded box and bounding sphere of a mesh from the exact box [lo, hi] of its triangle records' corners
+ * (v0, v0 + e1, v0 + e2); returns the pad, which the node boxes of the mesh's BVH take as well. */
+float mesh_bounds_from_box(const float lo[3], const float hi[3], uint32_t count, DMesh& mesh);
 /* Walks every triangle BVH of a built scene: each triangle of a BVH mesh sits in exactly one leaf, leaves hold
  * 1..4 triangles, every child box contains the (padded) boxes below it and its triangles' vertices, and no
  * root-to-leaf path has more than kBvhMaxDepth inner nodes.  max_depth returns the longest path found. */

@@ -1,0 +1,43 @@
+/* rt_bvh_device.h -- triangle BVH built on the GPU (see rt_bvh_device.hip). */
+#ifndef RT_BVH_DEVICE_H
+#define RT_BVH_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "rt_types.h"
+
+namespace rtd {
+
+struct DeviceBvh {
+    DBvhNode* nodes = nullptr; /* device array owned by the caller after a successful build (hipFree) */
+    uint32_t n_nodes = 0;
+    int32_t root = -1;         /* already offset by node_base */
+    int max_depth = 0;         /* inner nodes on the longest root-to-leaf path */
+    float sort_ms = 0.f, tree_ms = 0.f; /* device time: keys + sort + permutation, hierarchy + boxes */
+};
+
+/* Triangle records of one mesh, made on the device from the caller's vertex / index pools exactly as the host
+ * scene builder makes them (vertices times 1.000001f, two edge differences, R/src/Mesh.h:220-234; global vertex
+ * ids; tri_orig = identity).  d_tris / d_tri_orig point at the mesh's first record.  d_box: 8 words owned by
+ * the caller and initialised with box_init(): the exact box of all record corners (v0, v0 + e1, v0 + e2) in an
+ * order-preserving integer encoding (box_decode), then a flag that becomes 1 if a vertex index is
+ * >= n_vertices (such a triangle gets an all-zero record).  Only enqueues work on the stream. */
+void box_init(uint32_t box[8]);
+void box_decode(const uint32_t box[8], float lo[3], float hi[3], bool& bad_index);
+hipError_t make_mesh_tris(const float* d_positions, const uint32_t* d_triangles, uint32_t first_vertex, uint32_t n_vertices,
+                          uint32_t n_triangles, DTri* d_tris, uint32_t* d_tri_orig, uint32_t* d_box, hipStream_t stream);
+
+/* Builds the BVH of the triangles d_tris[first, first + count) -- records in the mesh's original order, as the
+ * host scene builder lays them out -- entirely on the device: the records are permuted into leaf order in
+ * place, d_tri_orig[first + i] receives the mesh-local original index of the record now at first + i, and the
+ * nodes come back in a fresh device array whose child indices are offset by node_base (the position the array
+ * will take in the scene's node table).  lo / hi: the mesh's padded box, pad: the padding every node box gets
+ * (both as the host builder computes them).  Returns hipSuccess or the failing HIP status; err says where. */
+hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, uint32_t count, const float lo[3],
+                          const float hi[3], float pad, int32_t node_base, int max_levels, hipStream_t stream,
+                          DeviceBvh& out, std::string& err);
+
+}  // namespace rtd
+#endif

@@ -1,0 +1,346 @@
+/*
+ * rt_bvh_device.hip -- per-mesh triangle BVH built on the GPU (gfx950).
+ *
+ * The reference has no such structure: Mesh::intersect loops over every triangle (R/src/Mesh.h:225).  A
+ * BVH only has to visit every triangle that loop would accept; which tree is used does not change a hit
+ * record (ties between equal t go to the lower original index, kept in tri_orig).  The host builder
+ * (rt_build.cpp, binned SAH) makes the better tree but needs ~0.1 us per triangle per level on one core;
+ * this one orders the triangles along a 63-bit Morton curve and cuts the sorted sequence top-down, all of
+ * it in device memory:
+ *
+ *   k_tri_keys      one thread per triangle: box centre -> 21 bits per axis (cubic cells) -> Morton key
+ *   rocprim sort    (key, triangle) pairs
+ *   k_permute       triangle records into sorted order (= leaf order), tri_orig
+ *   k_split         one launch per tree level, one thread per node of that level: the node's triangles are
+ *                   a range of the sorted sequence; cut it where the highest differing key bit flips
+ *                   (binary search), or at the median when the keys are equal or when
+ *                   depth + 1 + ceil(log2 count) would exceed the stack budget -- the host builder's rule,
+ *                   which keeps every root-to-leaf path within the 32 entries of the traversal stack.
+ *                   Ranges of <= 4 triangles become leaves; the others are queued for the next level.
+ *   rocprim scan    a node is named by its cut position (unique in a tree over a sequence): flags -> ranks
+ *                   give a numbering that does not depend on the order the queue was filled in
+ *   k_fit           levels in reverse: child boxes from the leaf triangles or from the finished child node,
+ *                   padded exactly as the host builder pads them
+ */
+#include "rt_bvh_device.h"
+
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace rtd {
+namespace {
+
+const uint32_t kLeafMax = 4;
+
+struct Item {          /* one inner node while the tree is being cut */
+    uint32_t lo, hi;   /* its triangles: positions [lo, hi) of the sorted sequence */
+    uint32_t mid;      /* cut position = the node's name */
+    uint32_t kid[2];   /* queue positions of the children that are inner nodes */
+};
+
+__device__ inline uint64_t spread3(uint32_t v) { /* 21 bits -> every third bit */
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+struct F3 { float x, y, z; };
+
+__device__ inline void tri_box(const DTri& t, float lo[3], float hi[3]) {
+    for (int a = 0; a < 3; ++a) {
+        float p0 = t.v0[a], p1 = t.v0[a] + t.e1[a], p2 = t.v0[a] + t.e2[a];
+        lo[a] = fminf(fminf(lo[a], p0), fminf(p1, p2));
+        hi[a] = fmaxf(fmaxf(hi[a], p0), fmaxf(p1, p2));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tri_keys(const DTri* tris, uint32_t count, F3 lo, float cells_per_unit, uint64_t* keys,
+                                                  uint32_t* ids) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    tri_box(tris[i], blo, bhi);
+    const float org[3] = {lo.x, lo.y, lo.z};
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        float c = 0.5f * (blo[a] + bhi[a]);
+        float f = (c - org[a]) * cells_per_unit;
+        q[a] = (uint32_t)fminf(fmaxf(f, 0.f), 2097151.f); /* NaN -> 0 */
+    }
+    keys[i] = spread3(q[0]) << 2 | spread3(q[1]) << 1 | spread3(q[2]);
+    ids[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_permute(const DTri* src, const uint32_t* ids, uint32_t count, DTri* dst, uint32_t* tri_orig) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    uint32_t id = ids[i];
+    const float4* s = (const float4*)(src + id);
+    float4* d = (float4*)(dst + i);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    tri_orig[i] = id;
+}
+
+/* items [begin, end) are the nodes of one level; *n_items is the end of the queue */
+__global__ void __launch_bounds__(256) k_split(Item* items, uint32_t begin, uint32_t end, int depth, int budget, const uint64_t* keys,
+                                               uint32_t* flags, uint32_t* n_items, uint32_t capacity) {
+    uint32_t i = begin + blockIdx.x * 256u + threadIdx.x;
+    if (i >= end) return;
+    Item it = items[i];
+    const uint32_t cnt = it.hi - it.lo;
+    const uint64_t first = keys[it.lo], last = keys[it.hi - 1];
+    int log2c = 32 - __clz((int)(cnt - 1)); /* ceil(log2 cnt), cnt > 4 */
+    uint32_t mid = it.lo + cnt / 2;
+    if (first != last && depth + 1 + log2c <= budget) {
+        const int bit = 63 - __clzll((long long)(first ^ last));
+        const uint64_t pivot = (last >> bit) << bit; /* the common prefix, this bit set, zeros below */
+        uint32_t a = it.lo + 1, b = it.hi - 1;      /* smallest position with key >= pivot lies in [a, b] */
+        while (a < b) {
+            uint32_t m = a + (b - a) / 2;
+            if (keys[m] >= pivot) b = m; else a = m + 1;
+        }
+        mid = a;
+    }
+    it.mid = mid;
+    it.kid[0] = it.kid[1] = 0xffffffffu;
+    flags[mid] = 1u;
+    const uint32_t lo[2] = {it.lo, mid}, hi[2] = {mid, it.hi};
+    for (int k = 0; k < 2; ++k) {
+        if (hi[k] - lo[k] <= kLeafMax) continue;
+        uint32_t at = atomicAdd(n_items, 1u);
+        if (at < capacity) { /* cannot overflow: a sequence of n has at most n - 1 cuts */
+            Item ch; ch.lo = lo[k]; ch.hi = hi[k]; ch.mid = 0; ch.kid[0] = ch.kid[1] = 0xffffffffu;
+            items[at] = ch;
+            it.kid[k] = at;
+        }
+    }
+    items[i] = it;
+}
+
+__global__ void __launch_bounds__(256) k_fit(const Item* items, uint32_t begin, uint32_t end, const uint32_t* rank, const DTri* tris,
+                                             uint32_t first, int32_t node_base, float pad, DBvhNode* nodes) {
+    uint32_t i = begin + blockIdx.x * 256u + threadIdx.x;
+    if (i >= end) return;
+    const Item it = items[i];
+    const uint32_t lo[2] = {it.lo, it.mid}, hi[2] = {it.mid, it.hi};
+    DBvhNode out;
+    float* olo[2] = {out.lo0, out.lo1};
+    float* ohi[2] = {out.hi0, out.hi1};
+    int32_t c[2], n[2];
+    for (int k = 0; k < 2; ++k) {
+        if (it.kid[k] == 0xffffffffu) { /* leaf: box of its triangles, then the pad */
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t t = lo[k]; t < hi[k]; ++t) tri_box(tris[t], blo, bhi);
+            for (int a = 0; a < 3; ++a) { olo[k][a] = blo[a] - pad; ohi[k][a] = bhi[a] + pad; }
+            c[k] = (int32_t)(first + lo[k]);
+            n[k] = (int32_t)(hi[k] - lo[k]);
+        } else { /* inner child, finished by the previous launch: union of its (padded) child boxes */
+            const uint32_t r = rank[items[it.kid[k]].mid];
+            const DBvhNode ch = nodes[r];
+            for (int a = 0; a < 3; ++a) { olo[k][a] = fminf(ch.lo0[a], ch.lo1[a]); ohi[k][a] = fmaxf(ch.hi0[a], ch.hi1[a]); }
+            c[k] = node_base + (int32_t)r;
+            n[k] = 0;
+        }
+    }
+    out.c0 = c[0]; out.n0 = n[0]; out.c1 = c[1]; out.n1 = n[1];
+    nodes[rank[it.mid]] = out;
+}
+
+/* floats as unsigned integers in the same order (-inf lowest), for atomicMin / atomicMax */
+__host__ __device__ inline uint32_t ordered(float f) {
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float unordered(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+__global__ void __launch_bounds__(256) k_make_tris(const float* positions, const uint32_t* triangles, uint32_t first_vertex, uint32_t n_vertices,
+                                                   uint32_t n_triangles, DTri* tris, uint32_t* tri_orig, uint32_t* box) {
+    __shared__ float s_box[4][6];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (t < n_triangles) {
+        const uint32_t i0 = triangles[3 * (size_t)t], i1 = triangles[3 * (size_t)t + 1], i2 = triangles[3 * (size_t)t + 2];
+        DTri tr;
+        if (i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) {
+            atomicOr(&box[6], 1u);
+            memset(&tr, 0, sizeof(tr));
+        } else {
+            const float scaling = 1.000001f; /* R/src/Mesh.h:220 */
+            const float* p0 = positions + 3 * (size_t)i0;
+            const float* p1 = positions + 3 * (size_t)i1;
+            const float* p2 = positions + 3 * (size_t)i2;
+            for (int a = 0; a < 3; ++a) {
+                const float v0 = scaling * p0[a], v1 = scaling * p1[a], v2 = scaling * p2[a];
+                tr.v0[a] = v0; tr.e1[a] = v1 - v0; tr.e2[a] = v2 - v0;
+            }
+            tr.i0 = first_vertex + i0; tr.i1 = first_vertex + i1; tr.i2 = first_vertex + i2;
+            tri_box(tr, lo, hi);
+        }
+        float4* d = (float4*)(tris + t);
+        const float4* s = (const float4*)&tr;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        tri_orig[t] = t;
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+    if ((threadIdx.x & 63u) == 0)
+        for (int a = 0; a < 3; ++a) { s_box[threadIdx.x >> 6][a] = lo[a]; s_box[threadIdx.x >> 6][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = (int)threadIdx.x;
+        float v = s_box[0][k];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? fminf(v, s_box[w][k]) : fmaxf(v, s_box[w][k]);
+        if (k < 3) atomicMin(&box[k], ordered(v)); else atomicMax(&box[k], ordered(v));
+    }
+}
+
+struct Temps {
+    std::vector<void*> ptrs;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    ~Temps() {
+        for (void* p : ptrs) (void)hipFree(p);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    template <class T>
+    hipError_t get(T** out, size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T*)p;
+        return e;
+    }
+};
+
+inline unsigned blocks(uint32_t n) { return (n + 255u) / 256u; }
+
+}  // namespace
+
+#define BVH_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) { err = std::string("device BVH build: ") + #expr + ": " + hipGetErrorString(e_); return e_; } \
+    } while (0)
+
+void box_init(uint32_t box[8]) {
+    for (int a = 0; a < 3; ++a) { box[a] = ordered(INFINITY); box[3 + a] = ordered(-INFINITY); }
+    box[6] = box[7] = 0;
+}
+
+void box_decode(const uint32_t box[8], float lo[3], float hi[3], bool& bad_index) {
+    for (int a = 0; a < 3; ++a) { lo[a] = unordered(box[a]); hi[a] = unordered(box[3 + a]); }
+    bad_index = box[6] != 0;
+}
+
+hipError_t make_mesh_tris(const float* d_positions, const uint32_t* d_triangles, uint32_t first_vertex, uint32_t n_vertices,
+                          uint32_t n_triangles, DTri* d_tris, uint32_t* d_tri_orig, uint32_t* d_box, hipStream_t stream) {
+    if (n_triangles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_make_tris, dim3(blocks(n_triangles)), dim3(256), 0, stream, d_positions, d_triangles, first_vertex, n_vertices, n_triangles,
+                       d_tris, d_tri_orig, d_box);
+    return hipGetLastError();
+}
+
+hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, uint32_t count, const float lo[3],
+                          const float hi[3], float pad, int32_t node_base, int max_levels, hipStream_t stream,
+                          DeviceBvh& out, std::string& err) {
+    out = DeviceBvh();
+    if (count <= kLeafMax || count > 0x7fffffffu) { err = "device BVH build: triangle count outside (4, 2^31)"; return hipErrorInvalidValue; }
+    Temps tmp;
+    for (hipEvent_t& e : tmp.ev) BVH_TRY(hipEventCreate(&e));
+    uint64_t *keys_a, *keys_b;
+    uint32_t *ids_a, *ids_b, *flags, *rank, *n_items;
+    DTri* sorted;
+    Item* items;
+    BVH_TRY(tmp.get(&keys_a, count)); BVH_TRY(tmp.get(&keys_b, count));
+    BVH_TRY(tmp.get(&ids_a, count)); BVH_TRY(tmp.get(&ids_b, count));
+    BVH_TRY(tmp.get(&sorted, count));
+    BVH_TRY(tmp.get(&items, count));
+    BVH_TRY(tmp.get(&flags, (size_t)count + 1)); BVH_TRY(tmp.get(&rank, (size_t)count + 1));
+    BVH_TRY(tmp.get(&n_items, 1));
+    size_t sort_bytes = 0, scan_bytes = 0;
+    BVH_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a, keys_b, ids_a, ids_b, (size_t)count, 0u, 63u, stream));
+    BVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flags, rank, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
+    char *sort_tmp, *scan_tmp;
+    BVH_TRY(tmp.get(&sort_tmp, sort_bytes)); BVH_TRY(tmp.get(&scan_tmp, scan_bytes));
+
+    /* keys: cubic cells over the longest edge of the mesh box, 2^21 along it */
+    float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    float cells_per_unit = (ext > 0.f && ext < INFINITY) ? 2097152.f / ext : 0.f;
+    DTri* mesh_tris = d_tris + first;
+    BVH_TRY(hipEventRecord(tmp.ev[0], stream));
+    hipLaunchKernelGGL(k_tri_keys, dim3(blocks(count)), dim3(256), 0, stream, (const DTri*)mesh_tris, count, F3{lo[0], lo[1], lo[2]}, cells_per_unit, keys_a, ids_a);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_a, keys_b, ids_a, ids_b, (size_t)count, 0u, 63u, stream));
+    hipLaunchKernelGGL(k_permute, dim3(blocks(count)), dim3(256), 0, stream, (const DTri*)mesh_tris, (const uint32_t*)ids_b, count, sorted, d_tri_orig + first);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(hipMemcpyAsync(mesh_tris, sorted, (size_t)count * sizeof(DTri), hipMemcpyDeviceToDevice, stream));
+    BVH_TRY(hipEventRecord(tmp.ev[1], stream));
+
+    /* hierarchy, one launch per level */
+    BVH_TRY(hipMemsetAsync(flags, 0, ((size_t)count + 1) * 4, stream));
+    Item root; root.lo = 0; root.hi = count; root.mid = 0; root.kid[0] = root.kid[1] = 0xffffffffu;
+    uint32_t one = 1;
+    BVH_TRY(hipMemcpyAsync(items, &root, sizeof(Item), hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipMemcpyAsync(n_items, &one, 4, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipStreamSynchronize(stream)); /* root and one live on this stack frame */
+    std::vector<uint32_t> level_end; /* level d = items [level_end[d-1], level_end[d]) */
+    uint32_t begin = 0, end = 1;
+    for (int depth = 0; begin < end; ++depth) {
+        if (depth >= max_levels) { err = "device BVH build: tree deeper than the traversal stack"; return hipErrorInvalidValue; }
+        hipLaunchKernelGGL(k_split, dim3(blocks(end - begin)), dim3(256), 0, stream, items, begin, end, depth, max_levels + 2, (const uint64_t*)keys_b,
+                           flags, n_items, count);
+        BVH_TRY(hipGetLastError());
+        uint32_t total = 0;
+        BVH_TRY(hipMemcpyAsync(&total, n_items, 4, hipMemcpyDeviceToHost, stream));
+        BVH_TRY(hipStreamSynchronize(stream));
+        if (total > count) { err = "device BVH build: node queue overflow"; return hipErrorInvalidValue; }
+        level_end.push_back(end);
+        begin = end; end = total;
+    }
+    const uint32_t n_nodes = end;
+    BVH_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, flags, rank, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
+    DBvhNode* nodes = nullptr;
+    BVH_TRY(hipMalloc((void**)&nodes, (size_t)n_nodes * sizeof(DBvhNode)));
+    hipError_t e = hipSuccess;
+    for (int d = (int)level_end.size() - 1; d >= 0 && e == hipSuccess; --d) {
+        const uint32_t b = d ? level_end[(size_t)d - 1] : 0u, en = level_end[(size_t)d];
+        hipLaunchKernelGGL(k_fit, dim3(blocks(en - b)), dim3(256), 0, stream, (const Item*)items, b, en, (const uint32_t*)rank, (const DTri*)mesh_tris, first,
+                           node_base, pad, nodes);
+        e = hipGetLastError();
+    }
+    Item root_done;
+    uint32_t root_rank = 0;
+    if (e == hipSuccess) e = hipEventRecord(tmp.ev[2], stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&root_done, items, sizeof(Item), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipMemcpy(&root_rank, rank + root_done.mid, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void)hipFree(nodes);
+        err = std::string("device BVH build: box pass: ") + hipGetErrorString(e);
+        return e;
+    }
+    out.nodes = nodes;
+    out.n_nodes = n_nodes;
+    out.root = node_base + (int32_t)root_rank;
+    out.max_depth = (int)level_end.size();
+    (void)hipEventElapsedTime(&out.sort_ms, tmp.ev[0], tmp.ev[1]);
+    (void)hipEventElapsedTime(&out.tree_ms, tmp.ev[1], tmp.ev[2]);
+    return hipSuccess;
+}
+
+}  // namespace rtd

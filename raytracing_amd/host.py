@@ -57,9 +57,9 @@ class HostScene:
     def desc(self):
         return lib().rth_scene_desc(self.h).contents
 
-    def upload(self):
-        """rt_scene_create on the current GPU."""
-        return api.DeviceScene(self.desc, keep=self)
+    def upload(self, flags=None):
+        """rt_scene_create (flags None) or rt_scene_create_ex on the current GPU."""
+        return api.DeviceScene(self.desc, keep=self, flags=flags)
 
     def __del__(self):
         if getattr(self, "h", None) and lib is not None:  # module globals are gone at interpreter exit

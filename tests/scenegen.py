@@ -6,7 +6,7 @@ import numpy as np
 
 
 def random_objects(api_mod, n_spheres=40, n_squares=24, seed=3, with_mesh=None, point_light=False, kd_max_leaf=30,
-                   kd_max_depth=15):
+                   kd_max_depth=15, second_mesh=None):
     """A box-like world of small spheres and squares; api_mod is oracle.orc or raytracing_amd.api (same layouts).
     Returns (desc, keepalive)."""
     rng = np.random.default_rng(seed)
@@ -51,17 +51,21 @@ def random_objects(api_mod, n_spheres=40, n_squares=24, seed=3, with_mesh=None, 
     d.spheres, d.squares, d.lights, d.materials = sph, sq, lights, mats
     keep = [mats, sph, sq, lights]
     if with_mesh is not None:
-        pos, nrm, tri = with_mesh
-        pos = np.ascontiguousarray(pos, np.float32)
-        nrm = np.ascontiguousarray(nrm, np.float32)
-        tri = np.ascontiguousarray(tri, np.uint32)
-        mesh = (api_mod.Mesh * 1)()
-        mesh[0].first_vertex, mesh[0].n_vertices = 0, len(pos)
-        mesh[0].first_triangle, mesh[0].n_triangles = 0, len(tri)
-        mesh[0].material = len(mats) - 1
-        mesh[0].aabb_min[:] = pos.min(0)
-        mesh[0].aabb_max[:] = pos.max(0)
-        d.n_meshes, d.meshes = 1, mesh
+        parts = [with_mesh] + ([second_mesh] if second_mesh is not None else [])
+        pos = np.ascontiguousarray(np.concatenate([p[0] for p in parts]), np.float32)
+        nrm = np.ascontiguousarray(np.concatenate([p[1] for p in parts]), np.float32)
+        tri = np.ascontiguousarray(np.concatenate([p[2] for p in parts]), np.uint32)   # indices stay mesh-local
+        mesh = (api_mod.Mesh * len(parts))()
+        v0 = t0 = 0
+        for k, (p, _, t) in enumerate(parts):
+            mesh[k].first_vertex, mesh[k].n_vertices = v0, len(p)
+            mesh[k].first_triangle, mesh[k].n_triangles = t0, len(t)
+            mesh[k].material = len(mats) - 1
+            mesh[k].aabb_min[:] = np.asarray(p, np.float32).min(0)
+            mesh[k].aabb_max[:] = np.asarray(p, np.float32).max(0)
+            v0 += len(p)
+            t0 += len(t)
+        d.n_meshes, d.meshes = len(parts), mesh
         d.n_vertices, d.n_triangles = len(pos), len(tri)
         d.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
         d.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))

@@ -1,0 +1,126 @@
+"""The triangle BVH built on the GPU (rt_scene_create_ex with RT_BUILD_BVH_DEVICE): the tree passes the host
+verifier, and hit records / images are those of the brute-force oracle and of the host-built tree.
+Run with -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracing_amd import api
+from tests import rayset, scenegen
+from tests.test_gpu_parity import assert_hits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    api.init(0)
+    yield
+
+
+def _pair(n_grid, seed, spheres=2, squares=5):
+    mesh = scenegen.grid_mesh(n_grid, seed=seed)
+    d, keep = scenegen.random_objects(orc, spheres, squares, seed, with_mesh=mesh)
+    o = orc.Scene.from_desc(d, keep)
+    return o, mesh
+
+
+def _mesh_rays(pos, n, seed):
+    rng = np.random.default_rng(seed)
+    org = rng.uniform(-1.9, 1.9, (n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(-0.9, 1.9, n).astype(np.float32)
+    tgt = pos[rng.integers(0, len(pos), n)] + rng.normal(scale=0.05, size=(n, 3)).astype(np.float32)
+    d = (tgt - org).astype(np.float32)
+    d[: n // 10] = rng.normal(size=(n // 10, 3)).astype(np.float32)
+    return org, orc.normalize_dirs(d)
+
+
+@pytest.mark.parametrize("n_grid", [7, 72])   # 72 triangles (just above the brute-force limit) and 10 082
+def test_device_built_tree_is_valid_and_exact(n_grid):
+    o, (pos, nrm, tri) = _pair(n_grid, seed=1)
+    g = api.DeviceScene(o.desc, keep=o, flags=api.BUILD_BVH_DEVICE)
+    info, times = g.verify()                       # every triangle in one leaf, boxes nested, depth within the stack
+    assert info.bvh_meshes == 1 and info.bvh_nodes > 0 and 1 <= info.bvh_max_depth <= 32
+    assert times.device_sort_ms > 0 and times.device_tree_ms > 0
+    org, d = _mesh_rays(pos, 20000, seed=41)
+    a = o.mesh_intersect(0, org, d)                # brute force over all triangles
+    b = g.mesh_intersect(0, org, d)
+    assert a["hit"].sum() > 5000
+    assert_hits_equal(a, b, "device-built bvh, mesh")
+    org, d = rayset.mixed(orc, n_each=1000)
+    assert_hits_equal(o.intersect(org, d), g.intersect(org, d), "device-built bvh, scene")
+    g.close()
+
+
+def test_device_and_host_trees_render_the_same_floats():
+    o, _ = _pair(48, seed=2)
+    gh = api.DeviceScene(o.desc, keep=o, flags=0)
+    gd = api.DeviceScene(o.desc, keep=o, flags=api.BUILD_BVH_DEVICE)
+    ih, td = gh.verify()
+    idv, _ = gd.verify()
+    assert ih.bvh_meshes == idv.bvh_meshes == 1
+    assert td.device_sort_ms == 0 and td.device_tree_ms == 0
+    w, h, spp = 48, 32, 2
+    cam = orc.camera_default(w, h)
+    a, sa = gh.render(cam, w, h, spp, seed=6, tile_w=8, tile_h=8)
+    b, sb = gd.render(cam, w, h, spp, seed=6, tile_w=8, tile_h=8)
+    assert (sa.rays, sa.nodes) == (sb.rays, sb.nodes)
+    assert a.tobytes() == b.tobytes()
+    img_o, so = o.render(cam, w, h, spp, orc.RT_RNG_COUNTER, seed=6, threads=4)
+    assert so.rays == sb.rays
+    ok = np.isfinite(img_o) & np.isfinite(b)
+    assert np.abs(img_o[ok] - b[ok]).max() <= 5e-6
+    gh.close(); gd.close()
+
+
+def test_two_meshes_and_degenerate_triangles():
+    """Two BVH meshes in one scene (node tables concatenated), one of them with all triangles collapsed into
+    a few points (equal Morton keys: median cuts) -- the tree must still verify and answer like the loop."""
+    pos1, nrm1, tri1 = scenegen.grid_mesh(12, seed=3)               # 242 triangles
+    pos2, nrm2, tri2 = scenegen.grid_mesh(10, seed=4)               # 162 triangles
+    pos2 = (np.round(pos2 * 2) / 2).astype(np.float32)              # snapped to a coarse lattice: many zero-area triangles
+    d, keep = scenegen.random_objects(orc, 1, 3, 5, with_mesh=(pos1, nrm1, tri1), second_mesh=(pos2, nrm2, tri2))
+    o = orc.Scene.from_desc(d, keep)
+    g = api.DeviceScene(o.desc, keep=o, flags=api.BUILD_BVH_DEVICE)
+    info, _ = g.verify()
+    assert info.bvh_meshes == 2
+    org, dd = _mesh_rays(np.concatenate([pos1, pos2]), 8000, seed=9)
+    for m in (0, 1):
+        assert_hits_equal(o.mesh_intersect(m, org, dd), g.mesh_intersect(m, org, dd), f"mesh {m}")
+    assert_hits_equal(o.intersect(org, dd), g.intersect(org, dd), "two meshes")
+    g.close()
+
+
+def test_unknown_flag_is_rejected():
+    o = orc.Scene.builtin(0)
+    with pytest.raises(api.RtError):
+        api.DeviceScene(o.desc, keep=o, flags=0x80)
+
+
+def test_small_mesh_records_made_on_the_device():
+    """Scene 3 (24-triangle star, no BVH): with the device option its triangle records and bounds come from
+    the GPU kernel; hit records and image must be those of the host-prepared scene."""
+    o = orc.Scene.builtin(3)
+    gh = api.DeviceScene(o.desc, keep=o, flags=0)
+    gd = api.DeviceScene(o.desc, keep=o, flags=api.BUILD_BVH_DEVICE)
+    info, _ = gd.verify()
+    assert info.bvh_meshes == 0 and info.bvh_nodes == 0
+    org, d = rayset.mixed(orc, n_each=1500)
+    a = o.intersect(org, d)
+    assert_hits_equal(a, gh.intersect(org, d), "host records")
+    assert_hits_equal(a, gd.intersect(org, d), "device records")
+    assert_hits_equal(o.mesh_intersect(0, org, d), gd.mesh_intersect(0, org, d), "device records, mesh")
+    w, h = 48, 48
+    cam = orc.camera_default(w, h)
+    assert gh.render(cam, w, h, 2, seed=4)[0].tobytes() == gd.render(cam, w, h, 2, seed=4)[0].tobytes()
+    gh.close(); gd.close()
+
+
+def test_bad_vertex_index_is_reported_by_both_builders():
+    pos, nrm, tri = scenegen.grid_mesh(12, seed=3)
+    tri = tri.copy()
+    tri[100, 1] = len(pos)                         # one past the mesh's vertices
+    d, keep = scenegen.random_objects(api, 1, 2, 5, with_mesh=(pos, nrm, tri))
+    for flags in (0, api.BUILD_BVH_DEVICE):
+        with pytest.raises(api.RtError, match="vertex index out of range"):
+            api.DeviceScene(d, keep=keep, flags=flags)

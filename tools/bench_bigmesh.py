@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scaling check of the triangle-BVH path: an n x n height field (2 (n-1)^2 triangles, built in memory, no OFF
 file) inside a box of squares with two spheres and the quad light, rendered at 1080p.  Prints build time,
-table size, Mrays/s and BVH work per ray.   usage: bench_bigmesh.py [--n 2237] [--spp 16] [--steps 2]"""
+table size, Mrays/s and BVH work per ray.   usage: bench_bigmesh.py [--n 2237] [--spp 16] [--steps 2] [--build host|device|both]"""
 import argparse
 import os
 import sys
@@ -19,6 +19,7 @@ ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--build", default="host", choices=["host", "device", "both"])
 a = ap.parse_args()
 
 n = a.n
@@ -34,17 +35,19 @@ nrm = np.zeros_like(pos)
 nrm[:, 1] = 1.0
 desc, keep = scenegen.random_objects(api, n_spheres=2, n_squares=6, seed=11, with_mesh=(pos, nrm, tri))
 print(f"mesh: {len(tri)} triangles, {len(pos)} vertices", flush=True)
-t0 = time.perf_counter()
-info = api.scene_check(desc)
-print(f"host build + verification {time.perf_counter() - t0:.2f} s: {info.bvh_nodes} BVH nodes, depth {info.bvh_max_depth}, "
-      f"{info.device_bytes / 1e6:.0f} MB of tables", flush=True)
 api.init(0)
-t0 = time.perf_counter()
-g = api.DeviceScene(desc, keep=keep)
-print(f"rt_scene_create {time.perf_counter() - t0:.2f} s", flush=True)
 cam = host.camera_default(a.width, a.height)
-for i in range(a.steps):
-    _, st = g.render_tiles(cam, a.width, a.height, a.spp, seed=1)
-    print(f"step {i}: {st.rays} rays, kernel {st.kernel_ms:.2f} ms, {st.rays / st.kernel_ms / 1e3:.1f} Mrays/s; BVH nodes/ray "
-          f"{st.bvh_nodes / st.rays:.2f}, triangles/ray {st.bvh_tris / st.rays:.2f}", flush=True)
-g.close()
+for build in (["host", "device"] if a.build == "both" else [a.build]):
+    t0 = time.perf_counter()
+    g = api.DeviceScene(desc, keep=keep, flags=api.BUILD_BVH_DEVICE if build == "device" else 0)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    info, tm = g.verify()   # reads the tables back and checks them on the host
+    print(f"[{build}] rt_scene_create {dt:.3f} s (host part {tm.host_ms:.0f} ms; device: keys + sort + permutation {tm.device_sort_ms:.2f} ms, "
+          f"hierarchy + boxes {tm.device_tree_ms:.2f} ms); verified in {time.perf_counter() - t0:.1f} s: {info.bvh_nodes} BVH nodes, "
+          f"depth {info.bvh_max_depth}, {info.device_bytes / 1e6:.0f} MB of tables", flush=True)
+    for i in range(a.steps):
+        _, st = g.render_tiles(cam, a.width, a.height, a.spp, seed=1)
+        print(f"[{build}] step {i}: {st.rays} rays, kernel {st.kernel_ms:.2f} ms, {st.rays / st.kernel_ms / 1e3:.1f} Mrays/s; BVH nodes/ray "
+              f"{st.bvh_nodes / st.rays:.2f}, triangles/ray {st.bvh_tris / st.rays:.2f}", flush=True)
+    g.close()
