@@ -196,13 +196,16 @@ int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches);
 int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out);
 int rt_scene_destroy(rt_scene_t scene);
 
-/* rt_scene_create with options.  RT_BUILD_BVH_DEVICE: the per-mesh triangle BVHs are built on the GPU from
- * the uploaded triangle records (Morton order, top-down cuts; milliseconds for millions of triangles) instead
- * of by the host's binned-SAH builder (a better tree, seconds for 10 M triangles).  Hit records do not depend
- * on the choice: the reference's Mesh::intersect is a loop over all triangles (R/src/Mesh.h:225), both trees
- * only have to reach every triangle it would accept.  rt_scene_create(desc, out) is
- * rt_scene_create_ex(desc, 0, out), or with RT_BUILD_BVH_DEVICE when the environment has
- * RTAMD_BVH_BUILD=device. */
+/* rt_scene_create with options.  RT_BUILD_BVH_DEVICE: everything per triangle is done on the GPU from the
+ * caller's vertex / index arrays -- the triangle records (R/src/Mesh.h:220-234 hoisted out of the ray loop),
+ * the mesh bounds and the per-mesh BVHs (Morton order, top-down cuts; milliseconds for millions of triangles)
+ * -- instead of by the host's loops and its binned-SAH builder (a somewhat better tree, seconds for 10 M
+ * triangles).  Hit records do not depend on the choice: the reference's Mesh::intersect is a loop over all
+ * triangles (R/src/Mesh.h:225), either tree only has to reach every triangle it would accept.
+ * rt_scene_create(desc, out) is rt_scene_create_ex(desc, 0, out) for scenes below
+ * RT_BUILD_AUTO_DEVICE_TRIANGLES triangles and rt_scene_create_ex(desc, RT_BUILD_BVH_DEVICE, out) from there
+ * on; the environment variable RTAMD_BVH_BUILD=host|device overrides that choice. */
+#define RT_BUILD_AUTO_DEVICE_TRIANGLES (1u << 20)
 #define RT_BUILD_BVH_DEVICE 1u
 int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* out);
 

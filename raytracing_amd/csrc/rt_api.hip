@@ -711,8 +711,12 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
 }
 
 int rt_scene_create(const rt_scene_desc* desc, rt_scene_t* out) {
+    /* host builder (the better tree) unless the meshes are so large that its seconds would dominate */
     const char* b = std::getenv("RTAMD_BVH_BUILD");
-    return rt_scene_create_ex(desc, (b && std::strcmp(b, "device") == 0) ? (uint32_t)RT_BUILD_BVH_DEVICE : 0u, out);
+    bool device = desc && desc->n_triangles >= RT_BUILD_AUTO_DEVICE_TRIANGLES;
+    if (b && std::strcmp(b, "device") == 0) device = true;
+    if (b && std::strcmp(b, "host") == 0) device = false;
+    return rt_scene_create_ex(desc, device ? (uint32_t)RT_BUILD_BVH_DEVICE : 0u, out);
 }
 
 int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times) {

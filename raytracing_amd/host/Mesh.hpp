@@ -7,6 +7,7 @@
 #pragma once
 #include <cfloat>
 #include <fstream>
+#include <limits>
 #include <string>
 #include <vector>
 #include "AABB.hpp"
@@ -58,19 +59,29 @@ public:
             }
     }
 
-    void loadOFF(const std::string& filename) { /* R/src/Mesh.cpp:21-39 */
+    /* R/src/Mesh.cpp:21-39.  Plain "OFF" files are read token by token exactly as the reference reads them (the
+     * corner count of a face is read and ignored, three indices follow).  "COFF" files carry colour values after
+     * each vertex position (and optionally after a face's indices); the reference's reader takes them for
+     * coordinates and cannot load such a file -- here the rest of the line is skipped. */
+    void loadOFF(const std::string& filename) {
         std::ifstream in(filename.c_str());
         if (!in) exit(EXIT_FAILURE);
         std::string tag;
         unsigned int nv, nt, ne;
         in >> tag >> nv >> nt >> ne;
+        const bool coloured = tag == "COFF";
+        const std::streamsize rest = std::numeric_limits<std::streamsize>::max();
         vertices.resize(nv);
         triangles.resize(nt);
-        for (unsigned int i = 0; i < nv; ++i) in >> vertices[i].position;
+        for (unsigned int i = 0; i < nv; ++i) {
+            in >> vertices[i].position;
+            if (coloured) in.ignore(rest, '\n');
+        }
         for (unsigned int i = 0; i < nt; ++i) {
             int corners;
             in >> corners;
             for (unsigned int j = 0; j < 3; ++j) in >> triangles[i].v[j];
+            if (coloured) in.ignore(rest, '\n');
         }
     }
 

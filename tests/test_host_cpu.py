@@ -113,3 +113,25 @@ def test_rt_write_ppm_p3_and_p6(tmp_path):
     assert open(ref).read().split() == text.split()
     with pytest.raises(api.RtError):
         api.write_ppm(str(tmp_path / "no" / "such" / "dir.ppm"), rgb8)
+
+
+def test_coff_file_loads_like_the_same_mesh_without_colours(tmp_path):
+    """loadOFF skips the per-vertex colours of a COFF file (the reference's reader cannot load one,
+    R/src/Mesh.cpp:30-31): positions, normals and triangles equal those of the plain OFF file."""
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(-1, 1, (40, 3)).astype(np.float32)
+    tri = np.array([[i % 40, (i + 1) % 40, (i + 7 + i // 40) % 40] for i in range(60)], np.uint32)
+    plain, coloured = tmp_path / "m.off", tmp_path / "m_c.off"
+    with open(plain, "w") as f:
+        f.write(f"OFF\n{len(pos)} {len(tri)} 0\n")
+        f.writelines(f"{p[0]!r} {p[1]!r} {p[2]!r}\n" for p in pos.tolist())
+        f.writelines(f"3 {t[0]} {t[1]} {t[2]}\n" for t in tri)
+    with open(coloured, "w") as f:
+        f.write(f"COFF\n{len(pos)} {len(tri)} 0\n")
+        f.writelines(f"{p[0]!r} {p[1]!r} {p[2]!r} {int(c[0])} {int(c[1])} {int(c[2])} 255\n" for p, c in zip(pos.tolist(), rng.integers(0, 256, (40, 3))))
+        f.writelines(f"3 {t[0]} {t[1]} {t[2]} 0.5 0.25 1.0\n" for t in tri)
+    a, b = host.HostScene.mesh_file(str(plain)), host.HostScene.mesh_file(str(coloured))
+    da, db = descutil.describe(a.desc), descutil.describe(b.desc)
+    assert a.desc.n_triangles == 60 and a.desc.n_vertices == 40
+    for k in da:
+        assert da[k] == db[k], f"{k} differs"
