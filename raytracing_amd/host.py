@@ -33,6 +33,7 @@ def lib():
         L.rth_camera_build.argtypes = [C.c_float] * 3 + [C.c_uint] * 2 + [C.c_float] * 4 + [C.POINTER(C.c_float),
                                                                                           C.POINTER(api.Camera)]
         L.rth_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint, C.c_uint]
+        L.rth_off_compare.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         _lib = L
     return _lib
 
@@ -65,6 +66,14 @@ class HostScene:
         if getattr(self, "h", None) and lib is not None:  # module globals are gone at interpreter exit
             lib().rth_scene_free(self.h)
             self.h = None
+
+
+def off_compare(path):
+    """Mesh::loadOFF against the reference's token-by-token reader on one file:
+    (identical, fast_reader_accepted, n_vertices, n_triangles)."""
+    nv, nt = C.c_uint(), C.c_uint()
+    r = lib().rth_off_compare(os.fsencode(path), C.byref(nv), C.byref(nt))
+    return bool(r & 1), bool(r & 2), nv.value, nt.value
 
 
 def camera_default(w, h):

@@ -13,6 +13,7 @@
 #include "AABB.hpp"
 #include "Device.hpp"
 #include "Material.hpp"
+#include "OffReader.hpp"
 #include "Ray.hpp"
 
 struct MeshVertex {
@@ -59,11 +60,25 @@ public:
             }
     }
 
-    /* R/src/Mesh.cpp:21-39.  Plain "OFF" files are read token by token exactly as the reference reads them (the
-     * corner count of a face is read and ignored, three indices follow).  "COFF" files carry colour values after
-     * each vertex position (and optionally after a face's indices); the reference's reader takes them for
-     * coordinates and cannot load such a file -- here the rest of the line is skipped. */
+    /* R/src/Mesh.cpp:21-39.  Plain decimal "OFF" files go through the multi-threaded reader (OffReader.hpp),
+     * which yields the values of the reference's token-by-token reader or declines; everything else is read
+     * by loadOFF_reference. */
     void loadOFF(const std::string& filename) {
+        std::vector<float> pos;
+        std::vector<unsigned int> idx;
+        if (!offreader::read(filename, pos, idx)) { loadOFF_reference(filename); return; }
+        vertices.resize(pos.size() / 3);
+        triangles.resize(idx.size() / 3);
+        for (size_t i = 0; i < vertices.size(); ++i) vertices[i].position = Vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        for (size_t i = 0; i < triangles.size(); ++i)
+            for (unsigned int j = 0; j < 3; ++j) triangles[i].v[j] = idx[3 * i + j];
+    }
+
+    /* The reference's reader, token by token (the corner count of a face is read and ignored, three indices
+     * follow).  "COFF" files carry colour values after each vertex position (and optionally after a face's
+     * indices); the reference takes them for coordinates and cannot load such a file -- here the rest of the
+     * line is skipped. */
+    void loadOFF_reference(const std::string& filename) {
         std::ifstream in(filename.c_str());
         if (!in) exit(EXIT_FAILURE);
         std::string tag;

@@ -49,6 +49,25 @@ void* rth_scene_mesh_file(const char* off_path, int with_spheres) {
     return h;
 }
 
+/* Reads an OFF file with Mesh::loadOFF and with the reference's token-by-token reader alone and compares the
+ * results bit for bit.  Returns bit 0 = identical, bit 1 = the multi-threaded reader accepted the file;
+ * counts come back through nv / nt. */
+int rth_off_compare(const char* path, unsigned* nv, unsigned* nt) {
+    Mesh a, b;
+    a.loadOFF(path);
+    b.loadOFF_reference(path);
+    std::vector<float> pos;
+    std::vector<unsigned int> idx;
+    const bool fast = offreader::read(path, pos, idx);
+    bool same = a.vertices.size() == b.vertices.size() && a.triangles.size() == b.triangles.size();
+    for (size_t i = 0; same && i < a.vertices.size(); ++i)
+        same = std::memcmp(&a.vertices[i].position[0], &b.vertices[i].position[0], 12) == 0;
+    for (size_t i = 0; same && i < a.triangles.size(); ++i) same = std::memcmp(a.triangles[i].v, b.triangles[i].v, 12) == 0;
+    if (nv) *nv = (unsigned)a.vertices.size();
+    if (nt) *nt = (unsigned)a.triangles.size();
+    return (same ? 1 : 0) | (fast ? 2 : 0);
+}
+
 const rt_scene_desc* rth_scene_desc(void* scene) { return &static_cast<HostScene*>(scene)->flat.desc; }
 void rth_scene_free(void* scene) { delete static_cast<HostScene*>(scene); }
 

@@ -135,3 +135,60 @@ def test_coff_file_loads_like_the_same_mesh_without_colours(tmp_path):
     assert a.desc.n_triangles == 60 and a.desc.n_vertices == 40
     for k in da:
         assert da[k] == db[k], f"{k} differs"
+
+
+def _write_off(path, tokens_v, faces, tag="OFF", nv=None, nt=None):
+    with open(path, "w") as f:
+        f.write(f"{tag}\n{nv if nv is not None else len(tokens_v) // 3} {nt if nt is not None else len(faces)} 0\n")
+        for i in range(0, len(tokens_v), 3):
+            f.write(" ".join(tokens_v[i:i + 3]) + "\n")
+        for fc in faces:
+            f.write(fc + "\n")
+
+
+def test_fast_off_reader_gives_the_token_readers_values(tmp_path):
+    """Decimal formats of every shape: short ones (exact fast path), long mantissas, big and tiny exponents,
+    values that round at the last bit -- loadOFF must equal the token-by-token reader bit for bit."""
+    rng = np.random.default_rng(11)
+    toks = []
+    for _ in range(3000):
+        x = float(np.float32(rng.normal() * 10.0 ** rng.integers(-12, 12)))
+        fmt = rng.choice(["%.7g", "%.9g", "%.17g", "%.3f", "%e", "%.12f", "%.4e", "%d"])
+        toks.append(fmt % (int(x) % 100000 if fmt == "%d" else x))
+    toks += ["0", "-0", "0.0", ".5", "-.25", "5.", "1e5", "1E-5", "16777215", "16777217", "0.1", "0.30000001192092896",
+             "1.17549435e-38", "3.40282347e38", "9999999", "1234567e-3", "0.000001234567", "8388608.5", "1e10", "1e-10", "1e11"]
+    toks += ["0"] * (-len(toks) % 3)
+    nv = len(toks) // 3
+    faces = [f"3 {i % nv} {(i * 7) % nv} {(i * 13 + 1) % nv}" for i in range(500)]
+    p = tmp_path / "a.off"
+    _write_off(p, toks, faces)
+    same, fast, n_v, n_t = host.off_compare(str(p))
+    assert fast and same and (n_v, n_t) == (nv, 500)
+    # a file large enough for several reader threads (> 1 MiB of text)
+    big_v = ["%.7g" % v for v in rng.normal(size=3 * 40000)]
+    big_f = [f"3 {i % 40000} {(i + 1) % 40000} {(i + 2) % 40000}" for i in range(80000)]
+    p2 = tmp_path / "big.off"
+    _write_off(p2, big_v, big_f)
+    assert os.path.getsize(p2) > (1 << 20)
+    assert host.off_compare(str(p2)) == (True, True, 40000, 80000)
+
+
+@pytest.mark.parametrize("case", ["plus", "inf", "hex", "short", "coff", "overflow", "junk", "negidx"])
+def test_fast_off_reader_declines_what_it_cannot_reproduce(tmp_path, case):
+    """Tokens whose treatment by operator>> is special (leading '+', inf, hex floats, range errors, junk, a file
+    that ends early, COFF): the fast reader must decline, so that loadOFF behaves exactly like the token reader."""
+    v = ["0.5", "1.5", "-2", "1", "2", "3", "4", "5", "6"]
+    faces = ["3 0 1 2", "3 2 1 0"]
+    tag, nv, nt = "OFF", None, None
+    if case == "plus": v[1] = "+1.5"
+    elif case == "inf": v[2] = "inf"
+    elif case == "hex": v[0] = "0x1p3"
+    elif case == "short": nt = 5            # header promises more faces than the file holds
+    elif case == "coff": tag = "COFF"
+    elif case == "overflow": v[4] = "1e40"
+    elif case == "junk": v[3] = "1.5abc"
+    elif case == "negidx": faces[1] = "3 2 -1 0"
+    p = tmp_path / f"{case}.off"
+    _write_off(p, v, faces, tag=tag, nv=nv, nt=nt)
+    same, fast, _, _ = host.off_compare(str(p))
+    assert same and not fast
