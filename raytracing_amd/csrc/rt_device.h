@@ -131,6 +131,17 @@ struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris
 #define RT_STACK_LDS 32      /* entries per lane, all in LDS: the host bounds the BVH depth to this (kBvhMaxDepth) */
 #define RT_STACK_STRIDE 256  /* workgroup size of the lane-per-ray kernels: lane-interleaved, conflict-free LDS layout */
 
+/* wave-level helpers: number of set bits of `mask` below `lane`; ordering of this wave's LDS accesses (the LDS
+ * unit serves one wave's requests in order: the fences only stop the compiler from moving them) */
+RT_DEV uint32_t wave_rank(uint64_t mask, uint32_t lane) {
+    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+RT_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 /* closest hit so far: enough to rebuild position and normal of the winner afterwards */
 struct HitRec {
     float t;    /* +inf while nothing was hit */
@@ -625,6 +636,70 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
 #pragma unroll
             for (int j = 0; j < RT_SB; ++j)
                 if (!occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j])) pend |= 1u << j;
+            /* The queues are uneven (typically half the lanes hold one ray, a tenth two): when the wave's
+             * queued rays fit in fewer rounds of one-ray-per-lane than the longest queue has entries, they
+             * are dealt out evenly first.  Ray g of the wave (ordered by slot j, then lane) goes to the
+             * g-th participating lane, round by round, through the wave's own stack words in LDS, which are
+             * idle between traversals; the answer comes back the same way.  Who walks a ray does not change
+             * its answer. */
+            const uint64_t lanes = __ballot(1);
+            const uint32_t n_lanes = (uint32_t)__popcll(lanes);
+            uint64_t has[RT_SB];
+            uint32_t before[RT_SB + 1];
+            before[0] = 0;
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j) { has[j] = __ballot((pend >> j) & 1u); before[j + 1] = before[j] + (uint32_t)__popcll(has[j]); }
+            const uint32_t total = before[RT_SB];
+            if (total == 0) continue;
+            const uint32_t own = (uint32_t)__popc(pend);
+            const uint32_t longest = __ballot(own >= 4) ? 4u : (__ballot(own >= 3) ? 3u : (__ballot(own >= 2) ? 2u : 1u));
+            const uint32_t rounds = (total + n_lanes - 1) / n_lanes;
+            if (rounds < longest) {
+                const uint32_t lane = __lane_id();
+                const uint32_t my = wave_rank(lanes, lane); /* position among the participating lanes */
+                uint32_t* const xb = cnt.stack - lane;     /* word x of the wave: xb[(x >> 6) * stride + (x & 63)] */
+                auto word = [&](uint32_t x) -> uint32_t& { return xb[(x >> 6) * cnt.stack_stride + (x & 63u)]; };
+                for (uint32_t r = 0; r < rounds; ++r) {
+                    const uint32_t lo = r * n_lanes, hi = lo + n_lanes;
+#pragma unroll
+                    for (int j = 0; j < RT_SB; ++j) {
+                        const uint32_t g = before[j] + wave_rank(has[j], lane);
+                        if (((pend >> j) & 1u) && g >= lo && g < hi) {
+                            const uint32_t x = (g - lo) * 7u;
+                            word(x) = __float_as_uint(o.x); word(x + 1) = __float_as_uint(o.y); word(x + 2) = __float_as_uint(o.z);
+                            word(x + 3) = __float_as_uint(d[j].x); word(x + 4) = __float_as_uint(d[j].y); word(x + 5) = __float_as_uint(d[j].z);
+                            word(x + 6) = __float_as_uint(dist[j]);
+                        }
+                    }
+                    wave_lds_sync();
+                    const bool mine = lo + my < total;
+                    f3 o2 = o, d2 = d[0];
+                    float dist2 = 0.f;
+                    if (mine) {
+                        const uint32_t x = my * 7u;
+                        o2 = mk3(__uint_as_float(word(x)), __uint_as_float(word(x + 1)), __uint_as_float(word(x + 2)));
+                        d2 = mk3(__uint_as_float(word(x + 3)), __uint_as_float(word(x + 4)), __uint_as_float(word(x + 5)));
+                        dist2 = __uint_as_float(word(x + 6));
+                    }
+                    wave_lds_sync(); /* every ray is in registers before any lane's stack overwrites the words */
+                    uint32_t answer = 0;
+                    if (mine) {
+                        float t, u, v;
+                        int tri;
+                        answer = bvh_walk<true>(sc, m, o2, d2, dist2, cnt, t, tri, u, v) ? 1u : 0u;
+                    }
+                    wave_lds_sync();
+                    if (mine) word(my) = answer;
+                    wave_lds_sync();
+#pragma unroll
+                    for (int j = 0; j < RT_SB; ++j) {
+                        const uint32_t g = before[j] + wave_rank(has[j], lane);
+                        if (((pend >> j) & 1u) && g >= lo && g < hi && word(g - lo)) hit |= 1u << j;
+                    }
+                    wave_lds_sync();
+                }
+                pend = 0;
+            }
             while (pend) {
                 const int j = __builtin_ctz(pend);
                 pend &= pend - 1;
