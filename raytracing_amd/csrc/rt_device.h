@@ -294,25 +294,27 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
     int cur = m.bvh_root;
     auto push = [&](int e) { cnt.stack[(sp++ & (RT_STACK_LDS - 1)) * cnt.stack_stride] = (uint32_t)e; }; /* never wraps: depth <= RT_STACK_LDS */
     auto pop = [&]() -> int { return (int)cnt.stack[(--sp & (RT_STACK_LDS - 1)) * cnt.stack_stride]; };
+    bool done = false;
+    auto visit = [&](const DBvhNode& n) { /* both child boxes of one inner node: where to go next */
+        ++cnt.bvh_nodes;
+        float t0, t1;
+        bool h0 = slab(n.lo0, n.hi0, o, id, best_t, t0) && !(n.n0 == 0 && n.c0 < 0);
+        bool h1 = slab(n.lo1, n.hi1, o, id, best_t, t1) && !(n.n1 == 0 && n.c1 < 0);
+        int e0 = n.n0 > 0 ? ~(n.c0 * 8 + n.n0) : n.c0;
+        int e1 = n.n1 > 0 ? ~(n.c1 * 8 + n.n1) : n.c1;
+        if (h0 && h1) {
+            bool first0 = t0 <= t1;
+            push(first0 ? e1 : e0);
+            cur = first0 ? e0 : e1;
+        } else if (h0) cur = e0;
+        else if (h1) cur = e1;
+        else if (sp > 0) cur = pop();
+        else done = true;
+    };
+    /* the root is the same node for every lane: its address is wave-uniform, so this fetch is a scalar load */
+    visit(ldc(&sc.bvh[m.bvh_root]));
     for (;;) {
-        bool done = false;
-        while (cur >= 0) { /* inner nodes */
-            const DBvhNode n = ldc(&sc.bvh[cur]);
-            ++cnt.bvh_nodes;
-            float t0, t1;
-            bool h0 = slab(n.lo0, n.hi0, o, id, best_t, t0) && !(n.n0 == 0 && n.c0 < 0);
-            bool h1 = slab(n.lo1, n.hi1, o, id, best_t, t1) && !(n.n1 == 0 && n.c1 < 0);
-            int e0 = n.n0 > 0 ? ~(n.c0 * 8 + n.n0) : n.c0;
-            int e1 = n.n1 > 0 ? ~(n.c1 * 8 + n.n1) : n.c1;
-            if (h0 && h1) {
-                bool first0 = t0 <= t1;
-                push(first0 ? e1 : e0);
-                cur = first0 ? e0 : e1;
-            } else if (h0) cur = e0;
-            else if (h1) cur = e1;
-            else if (sp > 0) cur = pop();
-            else { done = true; break; }
-        }
+        while (!done && cur >= 0) visit(ldc(&sc.bvh[cur])); /* inner nodes */
         if (done) break;
         { /* leaf */
             int code = ~cur;
