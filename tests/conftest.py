@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before librtamd.so is loaded: torch ships a HIP runtime of its own, and when the
+#                              system's is loaded first torch later finds "no HIP GPUs" in the same process
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
