@@ -417,6 +417,11 @@ struct Lib {
     uint32_t* order_ws[kOrderSlots] = {};
     size_t order_cap[kOrderSlots] = {};
     unsigned order_next = 0;
+    /* the launch order of the latest probe and what it was made for: the later passes of a progressive render
+     * (sample0 > 0, same stream, everything else unchanged) use it again instead of probing the same path trees once more */
+    struct OrderKey { rt_scene_t scene; void* stream; rt_camera cam; uint32_t w, h, tile_w, tile_h, rank, world; };
+    OrderKey order_key{};
+    int order_last_slot = -1;
     bool order_tiles = true;    /* RTAMD_TILE_ORDER=0 renders the tiles in index order */
     std::map<rt_scene_t, SceneRes*> scenes;
     rt_scene_t next_handle = 1;
@@ -529,6 +534,7 @@ int rt_shutdown(void) {
     (void)hipFree(g.cam_ring);
     g.cam_ring = nullptr;
     for (unsigned i = 0; i < kOrderSlots; ++i) { (void)hipFree(g.order_ws[i]); g.order_ws[i] = nullptr; g.order_cap[i] = 0; }
+    g.order_last_slot = -1;
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
@@ -957,19 +963,28 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
     }
     const uint32_t* d_order = nullptr;
     if (g.order_tiles && r->has_bounce && rp.n_local_tiles > 1) { /* without bounces every tree has one node: nothing to order */
-        const unsigned slot = g.order_next++ % kOrderSlots;
-        const size_t words = 2 * (size_t)rp.n_local_tiles;
-        if (g.order_cap[slot] < words) {
-            /* hipFree waits for the device, so no launch still reads the old block */
-            if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
-            HIP_TRY(hipMalloc((void**)&g.order_ws[slot], words * 4));
-            g.order_cap[slot] = words;
+        Lib::OrderKey key;
+        std::memset(&key, 0, sizeof(key));
+        key.scene = scene; key.stream = hip_stream; key.cam = *cam; key.w = w; key.h = h; key.tile_w = tile_w; key.tile_h = tile_h; key.rank = rank; key.world = world;
+        if (sample0 > 0 && g.order_last_slot >= 0 && std::memcmp(&key, &g.order_key, sizeof(key)) == 0) {
+            d_order = g.order_ws[g.order_last_slot] + rp.n_local_tiles;
+        } else {
+            const unsigned slot = g.order_next++ % kOrderSlots;
+            const size_t words = 2 * (size_t)rp.n_local_tiles;
+            if (g.order_cap[slot] < words) {
+                /* hipFree waits for the device, so no launch still reads the old block */
+                if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
+                HIP_TRY(hipMalloc((void**)&g.order_ws[slot], words * 4));
+                g.order_cap[slot] = words;
+            }
+            uint32_t* ws = g.order_ws[slot];
+            RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws);
+            hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
+            HIP_TRY(hipGetLastError());
+            d_order = ws + rp.n_local_tiles;
+            g.order_key = key;
+            g.order_last_slot = (int)slot;
         }
-        uint32_t* ws = g.order_ws[slot];
-        RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws);
-        hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
-        HIP_TRY(hipGetLastError());
-        d_order = ws + rp.n_local_tiles;
     }
     /* The samples of the call are cut so that every launch fills its waves: whole 64-sample chunks go to the
      * wave-per-pixel kernel, what is left to the packed kernel in pieces of at most 32 (2 pixels per wave,

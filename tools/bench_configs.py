@@ -27,6 +27,7 @@ ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--ranks", default="")
 ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--pass-spp", type=int, default=16)
+ap.add_argument("--wave-times", action="store_true", help="needs RTAMD_LIB = a build with -DRT_WAVE_TIMES: clocks of the waves of one pass")
 a = ap.parse_args()
 
 api.init(0)
@@ -82,6 +83,30 @@ out = torch.zeros(lay.buffer_floats(), dtype=torch.float32, device=dev)
 cnt = parallel_render.new_counters(dev)
 ranks = [int(x) for x in a.ranks.split(",")] if a.ranks else list(range(a.world))
 stream = torch.cuda.current_stream(dev)
+if a.wave_times:
+    import ctypes as C
+    L = api.lib()
+    L.rt_debug_wave_times.argtypes = [C.c_void_p]
+    per_wave = max(1, 64 // pass_spp) if pass_spp <= 32 else 1
+    n_waves = lay.per_rank * ((tw * th + per_wave - 1) // per_wave)
+    buf = torch.zeros(n_waves * 3, dtype=torch.int64, device=dev)
+    assert L.rt_debug_wave_times(buf.data_ptr()) == 0
+    for rank in ranks:
+        for rep in range(2):
+            buf.zero_()
+            scene.render_pass_device(cam, w, h, min(pass_spp, spp), 0, spp, 1, tw, th, rank, a.world, out.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+        t = buf.cpu().numpy().reshape(-1, 3)
+        t = t[t[:, 1] > 0]
+        t0 = t[:, 0].min()
+        st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0   # us at 100 MHz
+        dur = en - st
+        print(f"rank {rank}: {len(t)} waves, launch span {en.max():.0f} us, sum of wave times / 4096 slots {dur.sum() / 4096:.0f} us, "
+              f"mean wave {dur.mean():.1f} us, max {dur.max():.0f} us; percentiles 50/90/99/99.9: {[round(float(np.percentile(dur, q))) for q in (50, 90, 99, 99.9)]}")
+        for i in np.argsort(-en)[:10]:
+            print(f"   ends {en[i]:.0f} us  started {st[i]:.0f} us  ran {dur[i]:.0f} us  pixel ({t[i, 2] & 0xffffffff}, {t[i, 2] >> 32})")
+    scene.close()
+    sys.exit(0)
 worst = 0.0
 for rank in ranks:
     cnt.zero_()
