@@ -129,3 +129,48 @@ def device_render_fn(scene, cam, w, h, spp, seed, tile_w, tile_h, counters=None)
 
 def new_counters(device):
     return torch.zeros(api.COUNTER_SLOTS, api.COUNTER_STRIDE, dtype=torch.int64, device=device)
+
+
+class ProgressiveRenderer:
+    """Progressive accumulation over the same tile split: every pass adds spp_pass samples to the running sums
+    that stay in this rank's tile buffer (rt_render_pass_device semantics: the pass that reaches spp_total
+    divides by it), and nothing is exchanged until display() gathers the buffers on rank 0.
+
+    render_pass_fn(out, rank, world, sample0, spp_pass, spp_total) renders one pass into `out`."""
+
+    def __init__(self, w, h, tile_w, tile_h, device, render_pass_fn, spp_total):
+        self.sharded = ShardedRenderer(w, h, tile_w, tile_h, device, None, pipelined=False)
+        self.render_pass_fn = render_pass_fn
+        self.spp_total = spp_total
+        self.done = 0
+
+    @property
+    def rank(self):
+        return self.sharded.rank
+
+    def add_pass(self, spp_pass):
+        """Samples [done, done + spp_pass) of every pixel of this rank's tiles; enqueued on the current stream."""
+        if spp_pass <= 0 or self.done + spp_pass > self.spp_total:
+            raise ValueError("pass outside the total sample count")
+        s = self.sharded
+        self.render_pass_fn(s.mine[0], s.rank, s.world, self.done, spp_pass, self.spp_total)
+        self.done += spp_pass
+
+    def display(self):
+        """Gather the tile buffers and return the image so far on rank 0 (None elsewhere): the running sums
+        divided by the samples taken, or the finished image once all samples are in."""
+        s = self.sharded
+        work = dist.gather(s.mine[0], s.gathered[0], dst=0, async_op=True) if s.world > 1 else None
+        img = s._finish((work, 0))
+        if img is None or self.done == 0 or self.done == self.spp_total:
+            return img
+        return img / float(self.done)
+
+
+def device_pass_fn(scene, cam, w, h, seed, tile_w, tile_h, counters=None):
+    """render_pass_fn for a real GPU: rt_render_pass_device on torch's current stream."""
+    def fn(out, rank, world, sample0, spp_pass, spp_total):
+        stream = torch.cuda.current_stream(out.device)
+        scene.render_pass_device(cam, w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank, world, out.data_ptr(),
+                                 counters.data_ptr() if counters is not None else 0, stream.cuda_stream)
+    return fn

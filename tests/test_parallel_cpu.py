@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from raytracing_amd import api
-from raytracing_amd.parallel_render import ShardedRenderer, TileLayout
+from raytracing_amd.parallel_render import ProgressiveRenderer, ShardedRenderer, TileLayout
 
 
 def expected_image(w, h):
@@ -85,6 +85,63 @@ def test_sharded_gather_reassembles_image(world, w, h, tw, th):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, tw, th, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def _progressive_worker(rank, world, port, w, h, tw, th, q):
+    """Passes of 3 + 5 + 8 samples: a stand-in pass adds spp_pass times the known image to the sums and divides
+    in the pass that reaches the total, like rt_render_pass_device; display() between passes must show the
+    known image (sum / samples so far), and nothing but display() may talk to the other ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        inner = fake_render_fn(w, h, tw, th)
+        calls = []
+
+        def pass_fn(out, r_, wd, sample0, spp_pass, spp_total):
+            calls.append((sample0, spp_pass, spp_total))
+            one = torch.zeros_like(out)
+            inner(one, r_, wd)
+            if sample0 == 0:
+                out.zero_()
+            out += one * float(spp_pass)
+            if sample0 + spp_pass == spp_total:
+                out /= float(spp_total)
+        r = ProgressiveRenderer(w, h, tw, th, torch.device("cpu"), pass_fn, 16)
+        ok = True
+        want = expected_image(w, h)
+        for k in (3, 5, 8):
+            r.add_pass(k)
+            img = r.display()
+            if rank == 0:
+                ok = ok and bool(np.allclose(img.numpy(), want, rtol=1e-6, atol=0))
+            else:
+                ok = ok and img is None
+        ok = ok and calls == [(0, 3, 16), (3, 5, 16), (8, 8, 16)]
+        try:
+            r.add_pass(1)
+            ok = False
+        except ValueError:
+            pass
+        if rank == 0:
+            q.put(ok)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_progressive_passes_gather_only_on_display():
+    world, w, h, tw, th = 2, 100, 37, 16, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_progressive_worker, args=(r, world, port, w, h, tw, th, q)) for r in range(world)]
     for p in procs:
         p.start()
     ok = q.get(timeout=120)
