@@ -555,7 +555,8 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
 #define RT_SB 4
 #endif
 template <int M>
-RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[RT_SB], const float dist[RT_SB], bool occ[RT_SB], Cnt& cnt) {
+RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[RT_SB], const float dist[RT_SB], bool occ[RT_SB], uint32_t& near,
+                         Cnt& cnt) {
     bool act[RT_SB];
     cnt.rays += RT_SB;
 #pragma unroll
@@ -630,94 +631,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     });
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
         const DMesh m = ldc(&sc.meshes[mi]);
-        if ((M & RT_M_BVH) && m.bvh_root >= 0) { /* large mesh: one BVH traversal per ray that comes near it */
-            /* Few rays of a batch come near the mesh, and in different lanes they are different rays.  Each
-             * lane queues its own (pend) and all lanes walk their next queued ray together: the number of
-             * walks a wave pays for is the longest queue, not one per ray index somebody needs. */
-            uint32_t pend = 0, hit = 0;
-#pragma unroll
-            for (int j = 0; j < RT_SB; ++j)
-                if (!occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j])) pend |= 1u << j;
-            /* The queues are uneven (typically half the lanes hold one ray, a tenth two): when the wave's
-             * queued rays fit in fewer rounds of one-ray-per-lane than the longest queue has entries, they
-             * are dealt out evenly first.  Ray g of the wave (ordered by slot j, then lane) goes to the
-             * g-th participating lane, round by round, through the wave's own stack words in LDS, which are
-             * idle between traversals; the answer comes back the same way.  Who walks a ray does not change
-             * its answer. */
-            const uint64_t lanes = __ballot(1);
-            const uint32_t n_lanes = (uint32_t)__popcll(lanes);
-            uint64_t has[RT_SB];
-            uint32_t before[RT_SB + 1];
-            before[0] = 0;
-#pragma unroll
-            for (int j = 0; j < RT_SB; ++j) { has[j] = __ballot((pend >> j) & 1u); before[j + 1] = before[j] + (uint32_t)__popcll(has[j]); }
-            const uint32_t total = before[RT_SB];
-            if (total == 0) continue;
-            const uint32_t own = (uint32_t)__popc(pend);
-            const uint32_t longest = __ballot(own >= 4) ? 4u : (__ballot(own >= 3) ? 3u : (__ballot(own >= 2) ? 2u : 1u));
-            const uint32_t rounds = (total + n_lanes - 1) / n_lanes;
-            if (rounds < longest) {
-                const uint32_t lane = __lane_id();
-                const uint32_t my = wave_rank(lanes, lane); /* position among the participating lanes */
-                uint32_t* const xb = cnt.stack - lane;     /* word x of the wave: xb[(x >> 6) * stride + (x & 63)] */
-                auto word = [&](uint32_t x) -> uint32_t& { return xb[(x >> 6) * cnt.stack_stride + (x & 63u)]; };
-                for (uint32_t r = 0; r < rounds; ++r) {
-                    const uint32_t lo = r * n_lanes, hi = lo + n_lanes;
-#pragma unroll
-                    for (int j = 0; j < RT_SB; ++j) {
-                        const uint32_t g = before[j] + wave_rank(has[j], lane);
-                        if (((pend >> j) & 1u) && g >= lo && g < hi) {
-                            const uint32_t x = (g - lo) * 7u;
-                            word(x) = __float_as_uint(o.x); word(x + 1) = __float_as_uint(o.y); word(x + 2) = __float_as_uint(o.z);
-                            word(x + 3) = __float_as_uint(d[j].x); word(x + 4) = __float_as_uint(d[j].y); word(x + 5) = __float_as_uint(d[j].z);
-                            word(x + 6) = __float_as_uint(dist[j]);
-                        }
-                    }
-                    wave_lds_sync();
-                    const bool mine = lo + my < total;
-                    f3 o2 = o, d2 = d[0];
-                    float dist2 = 0.f;
-                    if (mine) {
-                        const uint32_t x = my * 7u;
-                        o2 = mk3(__uint_as_float(word(x)), __uint_as_float(word(x + 1)), __uint_as_float(word(x + 2)));
-                        d2 = mk3(__uint_as_float(word(x + 3)), __uint_as_float(word(x + 4)), __uint_as_float(word(x + 5)));
-                        dist2 = __uint_as_float(word(x + 6));
-                    }
-                    wave_lds_sync(); /* every ray is in registers before any lane's stack overwrites the words */
-                    uint32_t answer = 0;
-                    if (mine) {
-                        float t, u, v;
-                        int tri;
-                        answer = bvh_walk<true>(sc, m, o2, d2, dist2, cnt, t, tri, u, v) ? 1u : 0u;
-                    }
-                    wave_lds_sync();
-                    if (mine) word(my) = answer;
-                    wave_lds_sync();
-#pragma unroll
-                    for (int j = 0; j < RT_SB; ++j) {
-                        const uint32_t g = before[j] + wave_rank(has[j], lane);
-                        if (((pend >> j) & 1u) && g >= lo && g < hi && word(g - lo)) hit |= 1u << j;
-                    }
-                    wave_lds_sync();
-                }
-                pend = 0;
-            }
-            while (pend) {
-                const int j = __builtin_ctz(pend);
-                pend &= pend - 1;
-                f3 dj = d[0];
-                float distj = dist[0];
-#pragma unroll
-                for (int k = 1; k < RT_SB; ++k)
-                    if (j == k) { dj = d[k]; distj = dist[k]; }
-                float t, u, v;
-                int tri;
-                if (bvh_walk<true>(sc, m, o, dj, distj, cnt, t, tri, u, v)) hit |= 1u << j;
-            }
-#pragma unroll
-            for (int j = 0; j < RT_SB; ++j) occ[j] = occ[j] || ((hit >> j) & 1u);
-            continue;
-        }
+        if ((M & RT_M_BVH) && m.bvh_root >= 0) continue; /* large meshes: after everything else, see below */
         for_each_record(sc.tris + m.first_tri, m.n_tris, [&](const DTri& tr, uint32_t) {
             f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
             f3 sv = o - ld3(tr.v0);
@@ -738,6 +652,18 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
     }
 #pragma unroll
     for (int j = 0; j < RT_SB; ++j) occ[j] = occ[j] && act[j];
+    /* Large meshes are not walked here: few rays come near one, and a wave would pay a whole traversal per batch
+     * for a handful of them.  The rays still undecided that reach the bounds of some mesh with a BVH are reported
+     * in `near` and walked later, all light samples of the shaded point together (walk_deferred). */
+    near = 0;
+    if (M & RT_M_BVH)
+        for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
+            const DMesh m = ldc(&sc.meshes[mi]);
+            if (m.bvh_root < 0) continue;
+#pragma unroll
+            for (int j = 0; j < RT_SB; ++j)
+                if (!occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j])) near |= 1u << j;
+        }
 }
 
 /* ---- random numbers ---------------------------------------------------------------------- */
@@ -746,6 +672,109 @@ struct Rng {
     /* (float)rand() / RAND_MAX with RAND_MAX converted to float = 2^31 (R/src/Scene.h:259-260) */
     RT_DEV float unit() { return (float)(int)rt_rand31(key, k++) / 2147483648.f; }
 };
+
+/* Light sample i of a shaded point (Scene::samplePointOnLight, R/src/Scene.h:252-276): calls k + 2 i and
+ * k + 2 i + 1 of the sample's random stream, wherever the caller is in that stream. */
+RT_DEV f3 light_sample(const Rng& at_first, uint32_t i, f3 p0, f3 p1, f3 p2) {
+    Rng r = at_first;
+    r.k += 2u * i;
+    float u = r.unit();
+    float v = r.unit();
+    if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+    return ((1.f - u - v) * p0 + u * p1) + v * p2;
+}
+
+/* The shadow rays of one shaded point that came near a mesh with a BVH (bit i of `near` = light sample i), walked
+ * for all 16 light samples at once.  Such rays are rare and long (a few per hundred, ~15 nodes each), and which
+ * lanes hold them is uneven: walked where they arise a wave pays a full traversal per batch for a few busy lanes.
+ * So the wave's rays are numbered (lane by lane), ray g goes to the (g mod lanes)-th participating lane, round by
+ * round, through the wave's own stack words in LDS, which are idle between traversals, and the answers come back
+ * the same way; who walks a ray does not change its answer.  When that needs no fewer rounds than the longest
+ * queue of a lane has entries, every lane walks its own.  A ray is rebuilt from the random stream where it is
+ * needed (light_sample and the two normalisations of shade) instead of being kept in registers.
+ * Returns the bits of the rays that hit a triangle before the light. */
+template <int M>
+RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_first, f3 p0, f3 p1, f3 p2, uint32_t near, Cnt& cnt) {
+    const uint64_t lanes = __ballot(1);
+    const uint32_t n_lanes = (uint32_t)__popcll(lanes);
+    const uint32_t own = (uint32_t)__popc(near);
+    uint32_t start = 0, total = 0, longest = 0; /* rays of the lanes below this one, of the wave, of its busiest lane */
+#pragma unroll
+    for (int b = 4; b >= 0; --b) {
+        const uint64_t bit = __ballot((own >> b) & 1u);
+        start += wave_rank(bit, 0) << b;
+        total += (uint32_t)__popcll(bit) << b;
+        const uint32_t t = longest | (1u << b);
+        if (__ballot(own >= t)) longest = t;
+    }
+    if (total == 0) return 0;
+    auto ray = [&](uint32_t i, f3& d, float& dist) {
+        f3 SP = light_sample(at_first, i, p0, p1, p2) - P;
+        d = norm3_unit(norm3_len(SP, dist));
+    };
+    auto any_mesh = [&](f3 ro, f3 rd, float rdist) {
+        bool hit = false;
+        for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
+            const DMesh m = ldc(&sc.meshes[mi]);
+            if (m.bvh_root < 0) continue;
+            float t, u, v;
+            int tri;
+            if (!hit && bvh_reaches<true>(m, ro, rd, rdist)) hit = bvh_walk<true>(sc, m, ro, rd, rdist, cnt, t, tri, u, v);
+        }
+        return hit;
+    };
+    uint32_t hit = 0;
+    const uint32_t rounds = (total + n_lanes - 1) / n_lanes;
+    if (rounds >= longest) { /* dealing out gains nothing */
+        for (uint32_t bits = near; bits; bits &= bits - 1) {
+            const uint32_t i = (uint32_t)__builtin_ctz(bits);
+            f3 d;
+            float dist;
+            ray(i, d, dist);
+            if (any_mesh(o, d, dist)) hit |= 1u << i;
+        }
+        return hit;
+    }
+    const uint32_t lane = __lane_id();
+    const uint32_t my = wave_rank(lanes, lane); /* position among the participating lanes */
+    uint32_t* const xb = cnt.stack - lane;     /* word x of the wave: xb[(x >> 6) * stride + (x & 63)] */
+    auto word = [&](uint32_t x) -> uint32_t& { return xb[(x >> 6) * cnt.stack_stride + (x & 63u)]; };
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t lo = r * n_lanes, hi = lo + n_lanes;
+        uint32_t g = start;
+        for (uint32_t bits = near; bits; bits &= bits - 1, ++g) {
+            if (g < lo || g >= hi) continue;
+            f3 d;
+            float dist;
+            ray((uint32_t)__builtin_ctz(bits), d, dist);
+            const uint32_t x = (g - lo) * 7u;
+            word(x) = __float_as_uint(o.x); word(x + 1) = __float_as_uint(o.y); word(x + 2) = __float_as_uint(o.z);
+            word(x + 3) = __float_as_uint(d.x); word(x + 4) = __float_as_uint(d.y); word(x + 5) = __float_as_uint(d.z);
+            word(x + 6) = __float_as_uint(dist);
+        }
+        wave_lds_sync();
+        const bool mine = lo + my < total;
+        f3 o2 = o, d2 = o;
+        float dist2 = 0.f;
+        if (mine) {
+            const uint32_t x = my * 7u;
+            o2 = mk3(__uint_as_float(word(x)), __uint_as_float(word(x + 1)), __uint_as_float(word(x + 2)));
+            d2 = mk3(__uint_as_float(word(x + 3)), __uint_as_float(word(x + 4)), __uint_as_float(word(x + 5)));
+            dist2 = __uint_as_float(word(x + 6));
+        }
+        wave_lds_sync(); /* every ray is in registers before any lane's stack overwrites the words */
+        uint32_t answer = 0;
+        if (mine) answer = any_mesh(o2, d2, dist2) ? 1u : 0u;
+        wave_lds_sync();
+        if (mine) word(my) = answer;
+        wave_lds_sync();
+        g = start;
+        for (uint32_t bits = near; bits; bits &= bits - 1, ++g)
+            if (g >= lo && g < hi && word(g - lo)) hit |= 1u << __builtin_ctz(bits);
+        wave_lds_sync();
+    }
+    return hit;
+}
 
 /* powf(x, y) for x >= 0 through double: x^16 (the Cornell shininess) by four exact-enough double
  * squarings, anything else through the double pow; rounded once to float. */
@@ -788,10 +817,13 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
             f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
             if (!(M & RT_M_KD)) {
                 const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
+                const Rng at_first = rng; /* the stream position of light sample 0 */
+                uint32_t dark = 0, near = 0; /* bit i: light sample i is occluded / still has to be walked through a BVH */
                 for (int i0 = 0; i0 < 16; i0 += RT_SB) {
                     f3 L[RT_SB], Ld[RT_SB];
                     float dist[RT_SB];
                     bool occ[RT_SB];
+                    uint32_t near4;
 #pragma unroll
                     for (int j = 0; j < RT_SB; ++j) {
                         float u = rng.unit();
@@ -802,10 +834,26 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
-                    shadow_batch<M>(sc, so, so_inside, Ld, dist, occ, cnt);
+                    shadow_batch<M>(sc, so, so_inside, Ld, dist, occ, near4, cnt);
+                    if (!(M & RT_M_BVH)) { /* every ray is decided: add the light terms in sample order right away */
 #pragma unroll
-                    for (int j = 0; j < RT_SB; ++j)
-                        if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
+                        for (int j = 0; j < RT_SB; ++j)
+                            if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < RT_SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
+                        near |= near4 << i0;
+                    }
+                }
+                if (M & RT_M_BVH) {
+                    /* the undecided rays of all 16 samples in one go, then the sum in sample order; a light direction
+                     * is cheaper to rebuild from the random stream than to keep over the traversals */
+                    if (__ballot(near != 0)) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
+                    for (uint32_t i = 0; i < 16; ++i) {
+                        if ((dark >> i) & 1u) continue;
+                        float len;
+                        light_term(sum, lt, m, N, V, norm3_len(light_sample(at_first, i, p0, p1, p2) - P, len));
+                    }
                 }
             } else
                 for (int i = 0; i < 16; ++i) {
