@@ -962,7 +962,10 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
         g.cam_last = *cam;
     }
     const uint32_t* d_order = nullptr;
-    if (g.order_tiles && r->has_bounce && rp.n_local_tiles > 1) { /* without bounces every tree has one node: nothing to order */
+    /* Without bounces every tree has one node: nothing to order.  With a triangle BVH in the scene the probe has to
+     * traverse it for every pixel (3.9 ms of a 29 ms frame on 10 M triangles) and the order it finds gains nothing:
+     * there the long waves are the ones whose shadow rays skim the mesh, which the probe does not see. */
+    if (g.order_tiles && r->has_bounce && !(r->mode & RT_M_BVH) && rp.n_local_tiles > 1) {
         Lib::OrderKey key;
         std::memset(&key, 0, sizeof(key));
         key.scene = scene; key.stream = hip_stream; key.cam = *cam; key.w = w; key.h = h; key.tile_w = tile_w; key.tile_h = tile_h; key.rank = rank; key.world = world;
