@@ -429,3 +429,44 @@ def test_progressive_renderer_matches_the_one_shot_image():
     torch.cuda.synchronize()
     assert r.display().cpu().numpy().tobytes() == want.tobytes()
     g.close()
+
+
+def test_full_size_frame_properties():
+    """The benchmark frame itself (Cornell box, 1920 x 1080, 64 spp), through properties that need no oracle run of
+    that size: the 8-rank split reproduces the 1-rank image and ray count bit for bit, four passes of 16 samples
+    reproduce the one-shot floats, the image is finite and non-negative, and six full pixel rows at 2 spp equal the
+    oracle's colours (same counter RNG, so the very same paths)."""
+    import torch
+    o = orc.Scene.builtin(2)
+    g = api.DeviceScene(o.desc, keep=o)
+    w, h, spp, tw, th = 1920, 1080, 64, 16, 16
+    cam = orc.camera_default(w, h)
+    ref, st = g.render(cam, w, h, spp, seed=1, tile_w=tw, tile_h=th)
+    assert st.samples == w * h * spp
+    assert np.isfinite(ref).all() and ref.min() >= 0.0   # no upper bound: the reference never clamps (R/src/Scene.h:713)
+    world = 8
+    per = api.tiles_per_rank(w, h, tw, th, 0, world)
+    buf = np.zeros((world, per * th * tw * 3), np.float32)
+    rays = nodes = 0
+    for r in range(world):
+        tiles, s = g.render_tiles(cam, w, h, spp, 1, tw, th, r, world)
+        buf[r, :tiles.size] = tiles.ravel()
+        rays += s.rays
+        nodes += s.nodes
+    assert (rays, nodes) == (st.rays, st.nodes)
+    assert np.array_equal(_bits(api.tiles_to_image(buf, w, h, tw, th, world)), _bits(ref))
+    dev = torch.device("cuda", 0)
+    n1 = api.tiles_per_rank(w, h, tw, th, 0, 1)
+    acc = torch.zeros(n1 * th * tw * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for s0 in range(0, spp, 16):
+        g.render_pass_device(cam, w, h, 16, s0, spp, 1, tw, th, 0, 1, acc.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    img = api.tiles_to_image(acc.cpu().numpy().reshape(1, -1), w, h, tw, th, 1)
+    assert np.array_equal(_bits(img), _bits(ref))
+    # the oracle on 6 full rows of the frame at 2 spp: the same counter RNG, hence the very same paths
+    sub_g, _ = g.render(cam, w, h, 2, seed=1, tile_w=tw, tile_h=th)
+    for y in (0, 217, 540, 700, 863, 1079):
+        row_o, _ = o.render(cam, w, h, 2, orc.RT_RNG_COUNTER, seed=1, y0=y, y1=y + 1, threads=2)
+        assert np.abs(sub_g[y] - row_o[y]).max() <= 5e-6, y
+    g.close()
