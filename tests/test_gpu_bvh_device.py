@@ -145,3 +145,24 @@ def test_full_size_mesh_host_and_device_trees_agree():
     assert a.tobytes() == b.tobytes()
     assert sb.bvh_nodes > 0 and sb.bvh_tris > 0
     gh.close(); gd.close()
+
+
+def test_rt_scene_create_builds_large_scenes_on_the_device():
+    """From 2^20 triangles on rt_scene_create chooses the device build by itself (the times say who built), a scene
+    without meshes takes the device option without complaint, and 1 500 rays agree with the host-built tree."""
+    o = orc.Scene.builtin(2)
+    g0 = api.DeviceScene(o.desc, keep=o, flags=api.BUILD_BVH_DEVICE)      # no mesh at all
+    org, d = rayset.mixed(orc, n_each=300)
+    assert_hits_equal(o.intersect(org, d), g0.intersect(org, d), "device option, no mesh")
+    g0.close()
+    pos, nrm, tri = scenegen.grid_mesh(726, seed=5)                       # 2 * 725^2 = 1 051 250 triangles
+    assert len(tri) >= 1 << 20
+    desc, keep = scenegen.random_objects(api, 2, 5, 3, with_mesh=(pos, nrm, tri))
+    auto = api.DeviceScene(desc, keep=keep)                               # rt_scene_create
+    host_built = api.DeviceScene(desc, keep=keep, flags=0)
+    _, t_auto = auto.verify()
+    _, t_host = host_built.verify()
+    assert t_auto.device_tree_ms > 0 and t_host.device_tree_ms == 0
+    org, d = _mesh_rays(pos, 1500, seed=12)
+    assert_hits_equal(host_built.intersect(org, d), auto.intersect(org, d), "auto (device) against host")
+    auto.close(); host_built.close()
