@@ -494,6 +494,14 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defe
     for (uint32_t i = 0; i < d.n_squares; ++i) out.refs.push_back(DRef{RT_SQUARE, (int32_t)i});
     for (uint32_t i = 0; i < d.n_meshes; ++i) out.refs.push_back(DRef{RT_MESH, (int32_t)i});
     build_node(d, out, root, 0, (int32_t)out.refs.size(), 0);
+    if (!out.kd.empty() && !out.kd[0].leaf) { /* leaves of a real tree read their objects' records in reference order */
+        out.ref_spheres.assign(out.refs.size(), DSphere{});
+        out.ref_squares.assign(out.refs.size(), DSquare{});
+        for (size_t r = 0; r < out.refs.size(); ++r) {
+            if (out.refs[r].type == RT_SPHERE) out.ref_spheres[r] = out.spheres[(size_t)out.refs[r].object];
+            if (out.refs[r].type == RT_SQUARE) out.ref_squares[r] = out.squares[(size_t)out.refs[r].object];
+        }
+    }
     out.kd_epsilon = d.kd_epsilon;
     return true;
 }

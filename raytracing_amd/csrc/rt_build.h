@@ -22,6 +22,8 @@ struct Built {
     std::vector<DLight> lights;
     std::vector<DKdNode> kd;   /* kd[0] = root, pre-order */
     std::vector<DRef> refs;    /* leaf slices, list order of the reference */
+    std::vector<DSphere> ref_spheres; /* with internal kd nodes: the records in reference order (see DeviceScene) */
+    std::vector<DSquare> ref_squares;
     float box_lo[3], box_hi[3];
     float kd_epsilon = 0.01f;
 };

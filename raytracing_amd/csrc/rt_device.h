@@ -375,6 +375,23 @@ RT_DEV bool mesh_any(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
     return false;
 }
 
+/* Certain misses of the two analytic tests, decided before their square root / division (leaves of a kd-tree with
+ * internal nodes test up to 30 objects per ray, most of them missed).
+ * Sphere: the reference's c is fl(|oc|)^2 - r^2, within 4e-7 |oc|^2 of dot(oc, oc) - r^2; the discriminant formed
+ * from the latter is off by less than 1e-6 (b^2 + 4a (|oc|^2 + r^2)), so below minus ten times that the exact one
+ * is negative.  Square: num * rcp(den) is within 1.5 * 2^-23 of the exact quotient, so below -1e-30 the correctly
+ * rounded t is negative (the rule shadow_batch uses).  NaN operands fail both comparisons and take the exact path. */
+RT_DEV bool sphere_surely_missed(const DSphere& s, f3 o, f3 d) {
+    f3 oc = o - ld3(s.c);
+    float a = dot3(d, d), b = dot3(2.f * d, oc), q = dot3(oc, oc);
+    float four_ac = 4.f * a * (q - s.r2);
+    return b * b - four_ac < -1e-5f * (b * b + __builtin_fabsf(four_ac) + 4.f * a * (q + s.r2));
+}
+RT_DEV bool square_surely_behind(const DSquare& q, f3 o, f3 d) {
+    f3 n = ld3(q.n);
+    return dot3(ld3(q.v0) - o, n) * __builtin_amdgcn_rcpf(dot3(d, n)) < -1e-30f;
+}
+
 /* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------ */
 template <int M>
 RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, Cnt& cnt, HitRec& best) {
@@ -384,9 +401,15 @@ RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d
         float t = 0.f, u = 0.f, v = 0.f;
         int tri = -1;
         bool ok;
-        if (ref.type == RT_SPHERE) ok = sphere_t(ldc(&sc.spheres[ref.object]), o, d, t);
-        else if (ref.type == RT_SQUARE) ok = square_t(ldc(&sc.squares[ref.object]), o, d, t);
-        else ok = mesh_closest<M>(sc, ldc(&sc.meshes[ref.object]), o, d, cnt, t, tri, u, v);
+        /* with internal nodes (M & RT_M_KD) the record sits at the reference's own position: its address does not
+         * wait for the reference to arrive */
+        if (ref.type == RT_SPHERE) {
+            const DSphere s = (M & RT_M_KD) ? ldc(&sc.ref_spheres[r]) : ldc(&sc.spheres[ref.object]);
+            ok = !sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t);
+        } else if (ref.type == RT_SQUARE) {
+            const DSquare q = (M & RT_M_KD) ? ldc(&sc.ref_squares[r]) : ldc(&sc.squares[ref.object]);
+            ok = !square_surely_behind(q, o, d) && square_t(q, o, d, t);
+        } else ok = mesh_closest<M>(sc, ldc(&sc.meshes[ref.object]), o, d, cnt, t, tri, u, v);
         if (ok) {
             any = true;
             if (best.type < 0 || t < best.t) { best.t = t; best.type = ref.type; best.obj = ref.object; best.tri = tri; best.u = u; best.v = v; }
@@ -439,8 +462,13 @@ RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, fl
     for (int r = first; r < first + count; ++r) {
         DRef ref = ldc(&sc.refs[r]);
         float t;
-        if (ref.type == RT_SPHERE) { if (sphere_t(ldc(&sc.spheres[ref.object]), o, d, t) && t < dist) return true; }
-        else if (ref.type == RT_SQUARE) { if (square_t(ldc(&sc.squares[ref.object]), o, d, t) && t < dist) return true; }
+        if (ref.type == RT_SPHERE) {
+            const DSphere s = (M & RT_M_KD) ? ldc(&sc.ref_spheres[r]) : ldc(&sc.spheres[ref.object]);
+            if (!sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t) && t < dist) return true;
+        } else if (ref.type == RT_SQUARE) {
+            const DSquare q = (M & RT_M_KD) ? ldc(&sc.ref_squares[r]) : ldc(&sc.squares[ref.object]);
+            if (!square_surely_behind(q, o, d) && square_t(q, o, d, t) && t < dist) return true;
+        }
         else { if (mesh_any<M>(sc, ldc(&sc.meshes[ref.object]), o, d, dist, cnt)) return true; }
     }
     return false;

@@ -98,6 +98,8 @@ struct DeviceScene {
     const DLight* lights;
     const DKdNode* kd;
     const DRef* refs;
+    const DSphere* ref_spheres; /* kd-tree with internal nodes only: the record of reference r, stored at r (valid where */
+    const DSquare* ref_squares; /* refs[r] names a sphere / a square): one fetch per object instead of two in a row   */
     uint32_t n_spheres, n_squares, n_meshes, n_lights;
     uint32_t n_kd, n_refs;
     float box_lo[3], box_hi[3];  /* root box = Scene::computeGlobalAABB */

@@ -6,7 +6,7 @@ import numpy as np
 
 
 def random_objects(api_mod, n_spheres=40, n_squares=24, seed=3, with_mesh=None, point_light=False, kd_max_leaf=30,
-                   kd_max_depth=15, second_mesh=None):
+                   kd_max_depth=15, second_mesh=None, diffuse_only=False):
     """A box-like world of small spheres and squares; api_mod is oracle.orc or raytracing_amd.api (same layouts).
     Returns (desc, keepalive)."""
     rng = np.random.default_rng(seed)
@@ -17,6 +17,8 @@ def random_objects(api_mod, n_spheres=40, n_squares=24, seed=3, with_mesh=None, 
         m.shininess = float(rng.choice([0.0, 16.0, 20.0, 7.5]))
         m.index_medium = float(rng.choice([1.0, 1.3, 1.5]))
         m.type = int(rng.choice([0, 0, 1, 2])) if i < n_spheres else 0
+        if diffuse_only:
+            m.type = 0
     sph = (api_mod.Sphere * max(n_spheres, 1))()
     for i in range(n_spheres):
         sph[i].center[:] = rng.uniform(-1.8, 1.8, 3).astype(np.float32)

@@ -14,11 +14,12 @@ ap.add_argument("--width", type=int, default=960)
 ap.add_argument("--height", type=int, default=540)
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--diffuse", action="store_true", help="no mirror / glass spheres: every path has one node")
 ap.add_argument("--mesh", type=int, default=0, help="add an n x n height-field mesh (BVH): kd + BVH variant")
 ap.add_argument("--leaf", type=int, default=30, help="kd_max_leaf (the reference uses 30; 1000 keeps the root a leaf: brute force over all objects)")
 a = ap.parse_args()
 mesh = scenegen.grid_mesh(a.mesh, seed=2) if a.mesh else None
-desc, keep = scenegen.random_objects(api, n_spheres=60, n_squares=30, seed=7, with_mesh=mesh, kd_max_leaf=a.leaf)
+desc, keep = scenegen.random_objects(api, n_spheres=60, n_squares=30, seed=7, with_mesh=mesh, kd_max_leaf=a.leaf, diffuse_only=a.diffuse)
 info = api.scene_check(desc)
 print(f"kd nodes {info.kd_nodes}, depth {info.kd_max_depth}, kernel variant {info.kernel_variant}", flush=True)
 api.init(0)
