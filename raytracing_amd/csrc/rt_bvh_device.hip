@@ -24,6 +24,7 @@
  */
 #include "rt_bvh_device.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -79,18 +80,34 @@ __global__ void __launch_bounds__(256) k_tri_keys(const DTri* tris, uint32_t cou
 }
 
 __global__ void __launch_bounds__(256) k_permute(const DTri* src, const uint32_t* ids, uint32_t count, DTri* dst, uint32_t* tri_orig) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
-    uint32_t id = ids[i];
-    const float4* s = (const float4*)(src + id);
-    float4* d = (float4*)(dst + i);
-    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
-    tri_orig[i] = id;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    __shared__ float4 s_rec[768];
+    if (i < count) {
+        const uint32_t id = ids[i];
+        const float4* s = (const float4*)(src + id);
+        s_rec[3 * threadIdx.x] = s[0]; s_rec[3 * threadIdx.x + 1] = s[1]; s_rec[3 * threadIdx.x + 2] = s[2];
+        tri_orig[i] = id;
+    }
+    __syncthreads();
+    float4* out4 = (float4*)dst + 3ull * blockIdx.x * 256u;
+    const uint64_t left = 3ull * count - 3ull * blockIdx.x * 256u;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t j = threadIdx.x + 256u * k;
+        if (j < left) out4[j] = s_rec[j];
+    }
 }
 
-/* items [begin, end) are the nodes of one level; *n_items is the end of the queue */
-__global__ void __launch_bounds__(256) k_split(Item* items, uint32_t begin, uint32_t end, int depth, int budget, const uint64_t* keys,
+/* items [level[depth], level[depth + 1]) are the nodes of this level; *n_items is the end of the queue.  k_level_end
+ * notes where the next level ends once a level is cut, so the host launches all levels without waiting for any. */
+__global__ void k_level_end(uint32_t* level, int depth, const uint32_t* n_items, uint32_t capacity) {
+    const uint32_t n = *n_items;
+    level[depth + 2] = n < capacity ? n : capacity;
+}
+
+__global__ void __launch_bounds__(256) k_split(Item* items, const uint32_t* level, int depth, int budget, const uint64_t* keys,
                                                uint32_t* flags, uint32_t* n_items, uint32_t capacity) {
+    const uint32_t begin = level[depth], end = level[depth + 1]; /* the grid is sized for the most a level can hold */
     uint32_t i = begin + blockIdx.x * 256u + threadIdx.x;
     if (i >= end) return;
     Item it = items[i];
@@ -169,30 +186,45 @@ __host__ __device__ inline float unordered(uint32_t u) {
 __global__ void __launch_bounds__(256) k_make_tris(const float* positions, const uint32_t* triangles, uint32_t first_vertex, uint32_t n_vertices,
                                                    uint32_t n_triangles, DTri* tris, uint32_t* tri_orig, uint32_t* box) {
     __shared__ float s_box[4][6];
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    __shared__ float4 s_rec[768];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (t < n_triangles) {
-        const uint32_t i0 = triangles[3 * (size_t)t], i1 = triangles[3 * (size_t)t + 1], i2 = triangles[3 * (size_t)t + 2];
-        DTri tr;
-        if (i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) {
-            atomicOr(&box[6], 1u);
-            memset(&tr, 0, sizeof(tr));
-        } else {
-            const float scaling = 1.000001f; /* R/src/Mesh.h:220 */
-            const float* p0 = positions + 3 * (size_t)i0;
-            const float* p1 = positions + 3 * (size_t)i1;
-            const float* p2 = positions + 3 * (size_t)i2;
-            for (int a = 0; a < 3; ++a) {
-                const float v0 = scaling * p0[a], v1 = scaling * p1[a], v2 = scaling * p2[a];
-                tr.v0[a] = v0; tr.e1[a] = v1 - v0; tr.e2[a] = v2 - v0;
+    /* a bounded grid walks the triangles in strides: the box then costs six atomics per workgroup of a few thousand,
+     * not of forty thousand (atomics on one address are served one after the other) */
+    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < n_triangles; base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t t = base + threadIdx.x;
+        if (t < n_triangles) {
+            const uint32_t i0 = triangles[3 * t], i1 = triangles[3 * t + 1], i2 = triangles[3 * t + 2];
+            DTri tr;
+            if (i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) {
+                atomicOr(&box[6], 1u);
+                memset(&tr, 0, sizeof(tr));
+            } else {
+                const float scaling = 1.000001f; /* R/src/Mesh.h:220 */
+                const float* p0 = positions + 3 * (size_t)i0;
+                const float* p1 = positions + 3 * (size_t)i1;
+                const float* p2 = positions + 3 * (size_t)i2;
+                for (int a = 0; a < 3; ++a) {
+                    const float v0 = scaling * p0[a], v1 = scaling * p1[a], v2 = scaling * p2[a];
+                    tr.v0[a] = v0; tr.e1[a] = v1 - v0; tr.e2[a] = v2 - v0;
+                }
+                tr.i0 = first_vertex + i0; tr.i1 = first_vertex + i1; tr.i2 = first_vertex + i2;
+                tri_box(tr, lo, hi);
             }
-            tr.i0 = first_vertex + i0; tr.i1 = first_vertex + i1; tr.i2 = first_vertex + i2;
-            tri_box(tr, lo, hi);
+            const float4* s = (const float4*)&tr;
+            s_rec[3 * threadIdx.x] = s[0]; s_rec[3 * threadIdx.x + 1] = s[1]; s_rec[3 * threadIdx.x + 2] = s[2];
+            tri_orig[t] = (uint32_t)t;
         }
-        float4* d = (float4*)(tris + t);
-        const float4* s = (const float4*)&tr;
-        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
-        tri_orig[t] = t;
+        __syncthreads();
+        { /* the 48-byte records leave through LDS so that neighbouring threads store neighbouring 16 bytes */
+            float4* out4 = (float4*)tris + 3ull * base;
+            const uint64_t left = 3ull * n_triangles - 3ull * base; /* float4s from this chunk's start to the end */
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                const uint32_t i = threadIdx.x + 256u * k;
+                if (i < left) out4[i] = s_rec[i];
+            }
+        }
+        __syncthreads();
     }
     for (int a = 0; a < 3; ++a)
         for (int off = 32; off > 0; off >>= 1) {
@@ -250,7 +282,8 @@ void box_decode(const uint32_t box[8], float lo[3], float hi[3], bool& bad_index
 hipError_t make_mesh_tris(const float* d_positions, const uint32_t* d_triangles, uint32_t first_vertex, uint32_t n_vertices,
                           uint32_t n_triangles, DTri* d_tris, uint32_t* d_tri_orig, uint32_t* d_box, hipStream_t stream) {
     if (n_triangles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_make_tris, dim3(blocks(n_triangles)), dim3(256), 0, stream, d_positions, d_triangles, first_vertex, n_vertices, n_triangles,
+    const unsigned grid = blocks(n_triangles) < 4096u ? blocks(n_triangles) : 4096u;
+    hipLaunchKernelGGL(k_make_tris, dim3(grid), dim3(256), 0, stream, d_positions, d_triangles, first_vertex, n_vertices, n_triangles,
                        d_tris, d_tri_orig, d_box);
     return hipGetLastError();
 }
@@ -298,20 +331,29 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
     BVH_TRY(hipMemcpyAsync(items, &root, sizeof(Item), hipMemcpyHostToDevice, stream));
     BVH_TRY(hipMemcpyAsync(n_items, &one, 4, hipMemcpyHostToDevice, stream));
     BVH_TRY(hipStreamSynchronize(stream)); /* root and one live on this stack frame */
-    std::vector<uint32_t> level_end; /* level d = items [level_end[d-1], level_end[d]) */
-    uint32_t begin = 0, end = 1;
-    for (int depth = 0; begin < end; ++depth) {
-        if (depth >= max_levels) { err = "device BVH build: tree deeper than the traversal stack"; return hipErrorInvalidValue; }
-        hipLaunchKernelGGL(k_split, dim3(blocks(end - begin)), dim3(256), 0, stream, items, begin, end, depth, max_levels + 2, (const uint64_t*)keys_b,
-                           flags, n_items, count);
+    uint32_t* level; /* level d = items [level[d], level[d + 1]) */
+    BVH_TRY(tmp.get(&level, (size_t)max_levels + 2));
+    const uint32_t first_levels[2] = {0u, 1u};
+    BVH_TRY(hipMemcpyAsync(level, first_levels, 8, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipStreamSynchronize(stream)); /* first_levels lives on this stack frame */
+    for (int depth = 0; depth < max_levels; ++depth) {
+        /* a level holds at most 2^depth nodes, and at most one per kLeafMax + 1 triangles */
+        const uint64_t most = std::min<uint64_t>(depth < 31 ? (1ull << depth) : (1ull << 31), (uint64_t)count / (kLeafMax + 1) + 1);
+        hipLaunchKernelGGL(k_split, dim3(blocks((uint32_t)most)), dim3(256), 0, stream, items, (const uint32_t*)level, depth, max_levels + 2,
+                           (const uint64_t*)keys_b, flags, n_items, count);
+        hipLaunchKernelGGL(k_level_end, dim3(1), dim3(1), 0, stream, level, depth, (const uint32_t*)n_items, count);
         BVH_TRY(hipGetLastError());
-        uint32_t total = 0;
-        BVH_TRY(hipMemcpyAsync(&total, n_items, 4, hipMemcpyDeviceToHost, stream));
-        BVH_TRY(hipStreamSynchronize(stream));
-        if (total > count) { err = "device BVH build: node queue overflow"; return hipErrorInvalidValue; }
-        level_end.push_back(end);
-        begin = end; end = total;
     }
+    std::vector<uint32_t> level_host((size_t)max_levels + 2);
+    uint32_t total = 0;
+    BVH_TRY(hipMemcpyAsync(level_host.data(), level, level_host.size() * 4, hipMemcpyDeviceToHost, stream));
+    BVH_TRY(hipMemcpyAsync(&total, n_items, 4, hipMemcpyDeviceToHost, stream));
+    BVH_TRY(hipStreamSynchronize(stream));
+    if (total > count) { err = "device BVH build: node queue overflow"; return hipErrorInvalidValue; }
+    if (level_host[(size_t)max_levels + 1] > level_host[(size_t)max_levels]) { err = "device BVH build: tree deeper than the traversal stack"; return hipErrorInvalidValue; }
+    std::vector<uint32_t> level_end; /* ends of the levels that hold nodes */
+    for (int depth = 0; depth < max_levels && level_host[(size_t)depth + 1] > level_host[(size_t)depth]; ++depth) level_end.push_back(level_host[(size_t)depth + 1]);
+    const uint32_t end = level_end.empty() ? 0u : level_end.back();
     const uint32_t n_nodes = end;
     BVH_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, flags, rank, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
     DBvhNode* nodes = nullptr;
