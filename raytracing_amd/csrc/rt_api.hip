@@ -473,6 +473,97 @@ struct Scratch {
     }
 };
 
+/* Device path of rt_scene_create_ex, part 1: triangle records and mesh bounds from the caller's raw vertex / index
+ * pools (rt_bvh_device.hip).  Fills r->dev.tris / tri_orig / normals and the bounds of r->host.meshes; the meshes
+ * large enough for a BVH come back in bvh_todo with the pad of their node boxes. */
+int meshes_on_device(const rt_scene_desc& desc, SceneRes* r, std::vector<uint32_t>& bvh_todo, std::vector<float>& bvh_pad) {
+    DeviceScene& d = r->dev;
+    const size_t n_mesh = r->host.meshes.size();
+    uint64_t total = 0;
+    for (const DMesh& m : r->host.meshes) total += m.n_tris;
+    Scratch tmp;
+    float* d_pos; uint32_t* d_idx; uint32_t* d_box; float* d_nrm = nullptr; DTri* d_tris = nullptr; uint32_t* d_orig = nullptr;
+    int rc;
+    if ((rc = tmp.get((void**)&d_pos, (size_t)desc.n_vertices * 12)) || (rc = tmp.get((void**)&d_idx, (size_t)desc.n_triangles * 12)) ||
+        (rc = tmp.get((void**)&d_box, n_mesh * 32))) return rc;
+    hipError_t e = hipSuccess;
+    if (desc.n_vertices) {
+        e = hipMalloc((void**)&d_nrm, (size_t)desc.n_vertices * 12);
+        if (e == hipSuccess) r->allocs.push_back(d_nrm);
+    }
+    if (e == hipSuccess && total) { e = hipMalloc((void**)&d_tris, (size_t)total * sizeof(DTri)); if (e == hipSuccess) r->allocs.push_back(d_tris); }
+    if (e == hipSuccess && total) { e = hipMalloc((void**)&d_orig, (size_t)total * 4); if (e == hipSuccess) r->allocs.push_back(d_orig); }
+    std::vector<uint32_t> boxes(n_mesh * 8);
+    for (size_t k = 0; k < n_mesh; ++k) rtd::box_init(&boxes[8 * k]);
+    if (e == hipSuccess && desc.n_vertices) e = hipMemcpyAsync(d_pos, desc.positions, (size_t)desc.n_vertices * 12, hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess && desc.n_vertices) e = hipMemcpyAsync(d_nrm, desc.normals, (size_t)desc.n_vertices * 12, hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess && desc.n_triangles) e = hipMemcpyAsync(d_idx, desc.triangles, (size_t)desc.n_triangles * 12, hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_box, boxes.data(), n_mesh * 32, hipMemcpyHostToDevice, g.stream);
+    for (size_t k = 0; k < n_mesh && e == hipSuccess; ++k) {
+        const rt_mesh& m = desc.meshes[k];
+        const DMesh& o = r->host.meshes[k];
+        e = rtd::make_mesh_tris(d_pos + 3 * (size_t)m.first_vertex, d_idx + 3 * (size_t)m.first_triangle, m.first_vertex, m.n_vertices, m.n_triangles,
+                                d_tris + o.first_tri, d_orig + o.first_tri, d_box + 8 * k, g.stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(boxes.data(), d_box, n_mesh * 32, hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) return fail(RT_E_HIP, std::string("rt_scene_create: triangle records: ") + hipGetErrorString(e));
+    for (size_t k = 0; k < n_mesh; ++k) {
+        float lo[3], hi[3];
+        bool bad = false;
+        rtd::box_decode(&boxes[8 * k], lo, hi, bad);
+        if (bad) return fail(RT_E_INVALID, "rt_scene_create: triangle vertex index out of range");
+        DMesh& o = r->host.meshes[k];
+        const float pad = rtb::mesh_bounds_from_box(lo, hi, o.n_tris, o);
+        if (o.n_tris > rtb::kBvhMinTris) { bvh_todo.push_back((uint32_t)k); bvh_pad.push_back(pad); }
+    }
+    d.tris = d_tris; d.tri_orig = d_orig; d.normals = d_nrm;
+    r->n_tris = (size_t)total;
+    r->n_normals = 3 * (size_t)desc.n_vertices;
+    return RT_OK;
+}
+
+/* Part 2: one BVH per mesh of bvh_todo, built from the records on the device; the node tables are joined into
+ * r->dev.bvh (child indices already carry each mesh's offset). */
+int bvhs_on_device(SceneRes* r, const std::vector<uint32_t>& bvh_todo, const std::vector<float>& bvh_pad) {
+    DeviceScene& d = r->dev;
+    std::vector<rtd::DeviceBvh> parts;
+    std::string err;
+    int32_t base = 0;
+    hipError_t e = hipSuccess;
+    for (size_t k = 0; k < bvh_todo.size() && e == hipSuccess; ++k) {
+        DMesh& m = r->host.meshes[bvh_todo[k]];
+        rtd::DeviceBvh b;
+        e = rtd::build_mesh_bvh(const_cast<DTri*>(d.tris), const_cast<uint32_t*>(d.tri_orig), m.first_tri, m.n_tris, m.lo, m.hi,
+                                bvh_pad[k], base, rtb::kBvhMaxDepth, g.stream, b, err);
+        if (e != hipSuccess) break;
+        m.bvh_root = b.root;
+        base += (int32_t)b.n_nodes;
+        r->times.device_sort_ms += b.sort_ms; r->times.device_tree_ms += b.tree_ms;
+        r->bvh_depth = b.max_depth > r->bvh_depth ? b.max_depth : r->bvh_depth;
+        parts.push_back(b);
+    }
+    DBvhNode* all = nullptr;
+    if (e == hipSuccess && parts.size() == 1) {
+        all = parts[0].nodes; parts.clear();
+    } else if (e == hipSuccess) {
+        e = hipMalloc((void**)&all, (size_t)base * sizeof(DBvhNode));
+        size_t at = 0;
+        for (size_t k = 0; k < parts.size() && e == hipSuccess; ++k) {
+            e = hipMemcpy(all + at, parts[k].nodes, (size_t)parts[k].n_nodes * sizeof(DBvhNode), hipMemcpyDeviceToDevice);
+            at += parts[k].n_nodes;
+        }
+        if (e != hipSuccess && all) { (void)hipFree(all); all = nullptr; }
+        if (e != hipSuccess) err = std::string("rt_scene_create: node table: ") + hipGetErrorString(e);
+    }
+    for (rtd::DeviceBvh& b : parts) (void)hipFree(b.nodes);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? RT_E_LIMIT : RT_E_HIP, err);
+    r->allocs.push_back(all);
+    d.bvh = all;
+    r->n_bvh = (size_t)base;
+    return RT_OK;
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 int make_render_params(uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
@@ -614,85 +705,8 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
     r->n_bvh = r->host.bvh.size();
     std::vector<uint32_t> bvh_todo; /* device path: meshes that get a BVH, and the pad of their node boxes */
     std::vector<float> bvh_pad;
-    if (device_bvh && !r->host.meshes.empty()) {
-        /* triangle records, mesh bounds and BVHs are made on the device from the caller's raw pools */
-        const size_t n_mesh = r->host.meshes.size();
-        uint64_t total = 0;
-        for (const DMesh& m : r->host.meshes) total += m.n_tris;
-        Scratch tmp;
-        float* d_pos; uint32_t* d_idx; uint32_t* d_box; float* d_nrm = nullptr; DTri* d_tris = nullptr; uint32_t* d_orig = nullptr;
-        hipError_t e = hipSuccess;
-        if ((rc = tmp.get((void**)&d_pos, (size_t)desc->n_vertices * 12)) || (rc = tmp.get((void**)&d_idx, (size_t)desc->n_triangles * 12)) ||
-            (rc = tmp.get((void**)&d_box, n_mesh * 32))) { release(r); return rc; }
-        if (desc->n_vertices) {
-            e = hipMalloc((void**)&d_nrm, (size_t)desc->n_vertices * 12);
-            if (e == hipSuccess) r->allocs.push_back(d_nrm);
-        }
-        if (e == hipSuccess && total) { e = hipMalloc((void**)&d_tris, (size_t)total * sizeof(DTri)); if (e == hipSuccess) r->allocs.push_back(d_tris); }
-        if (e == hipSuccess && total) { e = hipMalloc((void**)&d_orig, (size_t)total * 4); if (e == hipSuccess) r->allocs.push_back(d_orig); }
-        std::vector<uint32_t> boxes(n_mesh * 8);
-        for (size_t k = 0; k < n_mesh; ++k) rtd::box_init(&boxes[8 * k]);
-        if (e == hipSuccess && desc->n_vertices) e = hipMemcpyAsync(d_pos, desc->positions, (size_t)desc->n_vertices * 12, hipMemcpyHostToDevice, g.stream);
-        if (e == hipSuccess && desc->n_vertices) e = hipMemcpyAsync(d_nrm, desc->normals, (size_t)desc->n_vertices * 12, hipMemcpyHostToDevice, g.stream);
-        if (e == hipSuccess && desc->n_triangles) e = hipMemcpyAsync(d_idx, desc->triangles, (size_t)desc->n_triangles * 12, hipMemcpyHostToDevice, g.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_box, boxes.data(), n_mesh * 32, hipMemcpyHostToDevice, g.stream);
-        for (size_t k = 0; k < n_mesh && e == hipSuccess; ++k) {
-            const rt_mesh& m = desc->meshes[k];
-            const DMesh& o = r->host.meshes[k];
-            e = rtd::make_mesh_tris(d_pos + 3 * (size_t)m.first_vertex, d_idx + 3 * (size_t)m.first_triangle, m.first_vertex, m.n_vertices, m.n_triangles,
-                                    d_tris + o.first_tri, d_orig + o.first_tri, d_box + 8 * k, g.stream);
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(boxes.data(), d_box, n_mesh * 32, hipMemcpyDeviceToHost, g.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
-        if (e != hipSuccess) { release(r); return fail(RT_E_HIP, std::string("rt_scene_create: triangle records: ") + hipGetErrorString(e)); }
-        for (size_t k = 0; k < n_mesh; ++k) {
-            float lo[3], hi[3];
-            bool bad = false;
-            rtd::box_decode(&boxes[8 * k], lo, hi, bad);
-            if (bad) { release(r); return fail(RT_E_INVALID, "rt_scene_create: triangle vertex index out of range"); }
-            DMesh& o = r->host.meshes[k];
-            const float pad = rtb::mesh_bounds_from_box(lo, hi, o.n_tris, o);
-            if (o.n_tris > rtb::kBvhMinTris) { bvh_todo.push_back((uint32_t)k); bvh_pad.push_back(pad); }
-        }
-        d.tris = d_tris; d.tri_orig = d_orig; d.normals = d_nrm;
-        r->n_tris = (size_t)total;
-        r->n_normals = 3 * (size_t)desc->n_vertices;
-    }
-    if (!bvh_todo.empty()) { /* the triangle BVHs are built here, from the records on the device */
-        std::vector<rtd::DeviceBvh> parts;
-        int32_t base = 0;
-        hipError_t e = hipSuccess;
-        for (size_t k = 0; k < bvh_todo.size() && e == hipSuccess; ++k) {
-            DMesh& m = r->host.meshes[bvh_todo[k]];
-            rtd::DeviceBvh b;
-            e = rtd::build_mesh_bvh(const_cast<DTri*>(d.tris), const_cast<uint32_t*>(d.tri_orig), m.first_tri, m.n_tris, m.lo, m.hi,
-                                    bvh_pad[k], base, rtb::kBvhMaxDepth, g.stream, b, err);
-            if (e != hipSuccess) break;
-            m.bvh_root = b.root;
-            base += (int32_t)b.n_nodes;
-            r->times.device_sort_ms += b.sort_ms; r->times.device_tree_ms += b.tree_ms;
-            r->bvh_depth = b.max_depth > r->bvh_depth ? b.max_depth : r->bvh_depth;
-            parts.push_back(b);
-        }
-        DBvhNode* all = nullptr;
-        if (e == hipSuccess && parts.size() == 1) {
-            all = parts[0].nodes; parts.clear();
-        } else if (e == hipSuccess) {
-            e = hipMalloc((void**)&all, (size_t)base * sizeof(DBvhNode));
-            size_t at = 0;
-            for (size_t k = 0; k < parts.size() && e == hipSuccess; ++k) {
-                e = hipMemcpy(all + at, parts[k].nodes, (size_t)parts[k].n_nodes * sizeof(DBvhNode), hipMemcpyDeviceToDevice);
-                at += parts[k].n_nodes;
-            }
-            if (e != hipSuccess && all) { (void)hipFree(all); all = nullptr; }
-            if (e != hipSuccess) err = std::string("rt_scene_create: node table: ") + hipGetErrorString(e);
-        }
-        for (rtd::DeviceBvh& b : parts) (void)hipFree(b.nodes);
-        if (e != hipSuccess) { release(r); return fail(e == hipErrorInvalidValue ? RT_E_LIMIT : RT_E_HIP, err); }
-        r->allocs.push_back(all);
-        d.bvh = all;
-        r->n_bvh = (size_t)base;
-    }
+    if (device_bvh && !r->host.meshes.empty() && (rc = meshes_on_device(*desc, r, bvh_todo, bvh_pad))) { release(r); return rc; }
+    if (!bvh_todo.empty() && (rc = bvhs_on_device(r, bvh_todo, bvh_pad))) { release(r); return rc; }
     if ((rc = upload(r, r->host.meshes, &d.meshes))) { release(r); return rc; }
     d.n_spheres = (uint32_t)r->host.spheres.size(); d.n_squares = (uint32_t)r->host.squares.size();
     d.n_meshes = (uint32_t)r->host.meshes.size(); d.n_lights = (uint32_t)r->host.lights.size();
