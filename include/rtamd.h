@@ -141,14 +141,19 @@ typedef struct rt_stats {
     double kernel_ms;     /* device time of the render kernels (HIP events on the stream)   */
     uint64_t bvh_nodes;   /* triangle-BVH nodes fetched (64 B each)                          */
     uint64_t bvh_tris;    /* triangles tested inside BVH leaves (48 B each)                  */
+    uint64_t rays_skipped; /* of `rays`: shadow queries the reference issues for a glass node whose Phong colour it then
+                            * overwrites (R/src/Scene.h:626 vs :705) -- counted in `rays`, which stays the number of
+                            * Scene::computeIntersection calls of the reference, but not traced: rays - rays_skipped
+                            * queries were actually evaluated */
 } rt_stats;
 
 /* Work counters on the device: RT_COUNTER_SLOTS slots of RT_COUNTER_STRIDE uint64 each
- * ({rays, samples, nodes, bvh_nodes, bvh_tris, 0...}); a workgroup adds into slot (workgroup id % RT_COUNTER_SLOTS), so the
+ * ({rays, samples, nodes, bvh_nodes, bvh_tris, rays_skipped, 0...}); a workgroup adds into slot (workgroup id % RT_COUNTER_SLOTS), so the
  * atomics of a launch spread over many cache lines instead of serialising on one.  The totals are
  * the sums over the slots (rt_counters_total).  The caller zeroes the buffer. */
 #define RT_COUNTER_SLOTS 1024
 #define RT_COUNTER_STRIDE 8
+#define RT_COUNTER_FIELDS 6
 #define RT_COUNTER_WORDS (RT_COUNTER_SLOTS * RT_COUNTER_STRIDE)
 
 typedef uint64_t rt_scene_t;
@@ -294,14 +299,16 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
  * Between passes the buffer holds sums: divide by the samples so far to display it.
  * rt_render_device(.., spp, ..) = rt_render_pass_device(.., spp, 0, spp, ..).
  * Both calls only enqueue work on hip_stream.  The library keeps the per-call device state (inverted camera,
- * tile launch order) in rings of 64 and 8 slots: at most 8 render calls may be in flight at once. */
+ * tile launch order) in rings of 64 and 8 slots; a call that gets a slot whose last reader was enqueued on a
+ * different stream makes its own stream wait for that reader (an event per slot), so any number of calls may be
+ * in flight on any number of streams. */
 int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h,
                           uint32_t spp_pass, uint32_t sample0, uint32_t spp_total, uint32_t seed,
                           uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
                           float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
 /* d_counters: NULL, or a zeroed device buffer of RT_COUNTER_WORDS uint64 (see above).  Host helper:
- * totals {rays, samples, nodes, bvh_nodes, bvh_tris} of a counter buffer copied back to the host. */
-void rt_counters_total(const uint64_t* h_counters, uint64_t out5[5]);
+ * totals {rays, samples, nodes, bvh_nodes, bvh_tris, rays_skipped} of a counter buffer copied back to the host. */
+void rt_counters_total(const uint64_t* h_counters, uint64_t out[RT_COUNTER_FIELDS]);
 
 /* Scatter `world` gathered tile buffers (rank-major, each padded to max_tiles_per_rank tiles)
  * into a row-major w*h*3 image.  Host helper for the gather step. */

@@ -1007,7 +1007,7 @@ void orc_trace(orc_scene* h, const float* org, const float* dir, size_t n, const
         for (int a = 0; a < 3; ++a) rgb[3 * i + a] = col[a];
     }
     h->total += c;
-    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; stats->bvh_nodes = 0; stats->bvh_tris = 0; }
+    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; stats->bvh_nodes = 0; stats->bvh_tris = 0; stats->rays_skipped = 0; }
 }
 
 /* ray_trace_from_camera, R/main.cpp:170-203, rows [y0, y1) of a w x h image.  rgb is the full
@@ -1055,7 +1055,7 @@ void orc_render(orc_scene* h, const rt_camera* cam, uint32_t w, uint32_t hgt, ui
     Counters c;
     for (const Counters& x : cs) c += x;
     h->total += c;
-    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; stats->bvh_nodes = 0; stats->bvh_tris = 0; }
+    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; stats->bvh_nodes = 0; stats->bvh_tris = 0; stats->rays_skipped = 0; }
 }
 
 /* PPM quantisation, R/main.cpp:213: (int)(255.f * min(1.f, c)). */

@@ -60,7 +60,7 @@ class Camera(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("nodes", C.c_uint64), ("kernel_ms", C.c_double),
-                ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64)]
+                ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64), ("rays_skipped", C.c_uint64)]
 
 
 class BuildInfo(C.Structure):

@@ -41,6 +41,13 @@ struct RenderParams {
     uint32_t spp_total, pad[3];                   /* samples per pixel of the finished image */
 };
 
+RT_DEV Cnt new_cnt(uint32_t* stack, uint32_t stack_stride, float* frames = nullptr, uint32_t frame_stride = 0) {
+    Cnt c;
+    c.rays = 0; c.nodes = 0; c.bvh_nodes = 0; c.bvh_tris = 0; c.skipped = 0;
+    c.stack = stack; c.stack_stride = stack_stride; c.frames = frames; c.frame_stride = frame_stride;
+    return c;
+}
+
 /* sum of a per-lane counter over the wave, in every lane */
 RT_DEV uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -53,16 +60,17 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 template <int M>
 RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     if (!counters) return;
-    constexpr int N = (M & RT_M_BVH) ? 5 : 3; /* BVH work is only counted by the variants that traverse one */
-    __shared__ uint32_t part[5];
+    constexpr int N = RT_COUNTER_FIELDS;
+    __shared__ uint32_t part[N];
     if (threadIdx.x < N) part[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t v[5] = {wave_sum(c.rays), wave_sum(samples), wave_sum(c.nodes), 0u, 0u};
-    if (N == 5) { v[3] = wave_sum(c.bvh_nodes); v[4] = wave_sum(c.bvh_tris); }
+    uint32_t v[N] = {wave_sum(c.rays), wave_sum(samples), wave_sum(c.nodes), 0u, 0u, wave_sum(c.skipped)};
+    if (M & RT_M_BVH) { v[3] = wave_sum(c.bvh_nodes); v[4] = wave_sum(c.bvh_tris); } /* only these variants traverse one */
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < N; ++k) atomicAdd(&part[k], v[k]);
+        for (int k = 0; k < N; ++k)
+            if (v[k]) atomicAdd(&part[k], v[k]);
     __syncthreads();
-    if (threadIdx.x < N) {
+    if (threadIdx.x < N && part[threadIdx.x]) {
         uint64_t* slot = counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_STRIDE;
         atomicAdd((unsigned long long*)&slot[threadIdx.x], (unsigned long long)part[threadIdx.x]);
     }
@@ -73,6 +81,9 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
  * wave is done, and next to a glass-rim pixel that takes 3 ms the three neighbours' slots would sit idle
  * (measured: 27.7 -> 27.2 ms on the full frame, 3.74 -> 3.61 ms on the slowest of eight ranks). */
 #define RT_RENDER_WAVES 1
+#endif
+#ifndef RT_FRAME_LDS
+#define RT_FRAME_LDS 5 /* levels of the path-frame stack kept in LDS by the render variants without a BVH: 5 x 7 x 256 B = 8960 B per wave */
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4 /* waves per SIMD the render variants are compiled for (<= 128 VGPRs) */
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
         float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
         f3 o, d;
         primary_ray(*cam, u, v, o, d);
-        Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
+        Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
         Rng rng; rng.key = 0; rng.k = 0;
         (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
         deepest = max(deepest, cnt.nodes);
@@ -178,7 +189,12 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
     const bool in_image = has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
     __shared__ uint32_t s_stack[RT_STACK_LDS * 64 * RT_RENDER_WAVES];
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = 64 * RT_RENDER_WAVES;
+    /* path frames: the first L levels in LDS.  A variant without a BVH never touches s_stack (the compiler drops it), so at
+     * 4 waves / SIMD = 16 waves per CU each wave can have 10 KB of the CU's 160 KB; the variants that traverse a BVH
+     * need their LDS for the traversal stack and keep the frames in the per-lane array */
+    constexpr int L = (M & RT_M_BVH) ? 0 : RT_FRAME_LDS;
+    __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 64 * RT_RENDER_WAVES : 1];
+    Cnt cnt = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES, s_frames + (L ? threadIdx.x : 0), 64 * RT_RENDER_WAVES);
     uint32_t my_samples = 0;
     f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane of a pixel */
     if (in_image && rp.sample0 > 0) acc = ld3(dst);
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
             primary_ray(*cam, u, v, o, d);
-            col = trace_path<M>(sc, o, norm3_unit(d), rng, cnt);
+            col = trace_path<M, false, L>(sc, o, norm3_unit(d), rng, cnt);
             ++my_samples;
         }
         for (uint32_t i = 0; i < rp.spp; ++i) { /* every lane of the wave takes part in the shuffles */
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
                 float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
                 f3 o, d;
                 primary_ray(*cam, u, v, o, d);
-                col = trace_path<M>(sc, o, norm3_unit(d), rng, cnt); /* Ray(pos, dir) normalises again */
+                col = trace_path<M, false, L>(sc, o, norm3_unit(d), rng, cnt); /* Ray(pos, dir) normalises again */
                 ++my_samples;
             }
             /* image[x + y*w] += color, one sample after the other */
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(256) void k_intersect(DeviceScene sc, const float* 
     if (i >= n) return;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
+    Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
     HitRec rec = closest_rec<M>(sc, o, d, cnt);
     FullHit h = finish_hit(sc, rec, o, d);
     int tri = (h.hit && h.type == RT_MESH) ? (int)ldc(&sc.tri_orig[h.tri]) : -1;
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     HitRec rec; rec.type = -1; rec.obj = (int)mesh; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     const DMesh m = ldc(&sc.meshes[mesh]);
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
+    Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
     if (mesh_closest<RT_M_BVH>(sc, m, o, d, cnt, rec.t, rec.tri, rec.u, rec.v)) rec.type = RT_MESH;
     FullHit h = finish_hit(sc, rec, o, d);
     out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)ldc(&sc.tri_orig[h.tri]) : -1, rec.u, rec.v);
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __re
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt cnt; cnt.rays = 0; cnt.nodes = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0; cnt.stack = s_stack + threadIdx.x; cnt.stack_stride = RT_STACK_STRIDE;
+    Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
     uint32_t smp = 0;
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
@@ -411,12 +427,19 @@ struct Lib {
      * (the kernel reads its camera through a pointer so the 2 x 16 doubles never occupy registers) */
     DCamera* cam_ring = nullptr;
     unsigned cam_next = 0;
-    rt_camera cam_last{};       /* the camera in slot cam_last_slot: an unchanged camera is not uploaded again */
-    int cam_last_slot = -1;
+    rt_camera cam_last{};       /* the camera in slot cam_last_slot, uploaded on stream cam_last_stream: a call on the */
+    int cam_last_slot = -1;     /* same stream with the same camera does not upload it again                           */
+    void* cam_last_stream = nullptr;
     /* workspaces of k_tile_class / k_tile_place, one per render call in turn, grown on demand */
     uint32_t* order_ws[kOrderSlots] = {};
     size_t order_cap[kOrderSlots] = {};
     unsigned order_next = 0;
+    /* A ring slot is handed out again after kCamSlots / kOrderSlots further calls.  The launches that read it may
+     * still be queued on another stream by then, so each slot carries an event recorded behind its last reader and
+     * a new user on a different stream waits for it (same stream: the stream's own order suffices). */
+    hipEvent_t cam_done[kCamSlots] = {}, order_done[kOrderSlots] = {};
+    void* cam_stream[kCamSlots] = {}; void* order_stream[kOrderSlots] = {};
+    bool cam_used[kCamSlots] = {}, order_used[kOrderSlots] = {};
     /* the launch order of the latest probe and what it was made for: the later passes of a progressive render
      * (sample0 > 0, same stream, everything else unchanged) use it again instead of probing the same path trees once more */
     struct OrderKey { rt_scene_t scene; void* stream; rt_camera cam; uint32_t w, h, tile_w, tile_h, rank, world; };
@@ -607,6 +630,8 @@ int rt_init(int device) {
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipMalloc((void**)&g.cam_ring, kCamSlots * sizeof(DCamera)));
+    for (unsigned i = 0; i < kCamSlots; ++i) { HIP_TRY(hipEventCreateWithFlags(&g.cam_done[i], hipEventDisableTiming)); g.cam_used[i] = false; }
+    for (unsigned i = 0; i < kOrderSlots; ++i) { HIP_TRY(hipEventCreateWithFlags(&g.order_done[i], hipEventDisableTiming)); g.order_used[i] = false; }
     g.cam_next = 0;
     g.cam_last_slot = -1;
     const char* ord = std::getenv("RTAMD_TILE_ORDER");
@@ -626,6 +651,8 @@ int rt_shutdown(void) {
     g.cam_ring = nullptr;
     for (unsigned i = 0; i < kOrderSlots; ++i) { (void)hipFree(g.order_ws[i]); g.order_ws[i] = nullptr; g.order_cap[i] = 0; }
     g.order_last_slot = -1;
+    for (unsigned i = 0; i < kCamSlots; ++i) if (g.cam_done[i]) { (void)hipEventDestroy(g.cam_done[i]); g.cam_done[i] = nullptr; }
+    for (unsigned i = 0; i < kOrderSlots; ++i) if (g.order_done[i]) { (void)hipEventDestroy(g.order_done[i]); g.order_done[i] = nullptr; }
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
@@ -909,7 +936,7 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
     std::vector<uint64_t> slots(RT_COUNTER_WORDS);
-    uint64_t cnt[5];
+    uint64_t cnt[RT_COUNTER_FIELDS];
     HIP_TRY(hipMemcpyAsync(rgb, d_c, 12 * n, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -918,7 +945,7 @@ int rt_trace(rt_scene_t scene, const float* org, const float* dir, size_t n, con
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
-        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4];
+        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4]; stats->rays_skipped = cnt[5];
     }
     return RT_OK;
 }
@@ -931,10 +958,10 @@ void rt_normalize_dirs(const float* dir, size_t n, float* out) {
     }
 }
 
-void rt_counters_total(const uint64_t* h, uint64_t out5[5]) {
-    for (int k = 0; k < 5; ++k) out5[k] = 0;
+void rt_counters_total(const uint64_t* h, uint64_t out[RT_COUNTER_FIELDS]) {
+    for (int k = 0; k < RT_COUNTER_FIELDS; ++k) out[k] = 0;
     for (size_t s = 0; s < RT_COUNTER_SLOTS; ++s)
-        for (int k = 0; k < 5; ++k) out5[k] += h[s * RT_COUNTER_STRIDE + k];
+        for (int k = 0; k < RT_COUNTER_FIELDS; ++k) out[k] += h[s * RT_COUNTER_STRIDE + k];
 }
 
 size_t rt_tiles_per_rank(uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world) {
@@ -948,9 +975,11 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     return rt_render_pass_device(scene, cam, w, h, spp, 0, spp, seed, tile_w, tile_h, rank, world, d_rgb_tiles, d_counters, hip_stream);
 }
 
-int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass, uint32_t sample0,
-                          uint32_t spp_total, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
-                          float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
+/* One pass of a render, enqueued on `st`: the camera goes to the next slot of the camera ring and the launch order to the
+ * next workspace of the order ring. */
+static int render_pass(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass,
+                       uint32_t sample0, uint32_t spp_total, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
+                       float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_render: call rt_init first");
     SceneRes* r = find(scene);
     if (!r) return fail(RT_E_HANDLE, "rt_render: unknown scene");
@@ -962,46 +991,60 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
     if (rc) return rc;
     rp.sample0 = sample0; rp.spp_total = spp_total;
     DCamera dc;
-    std::string err;
-    if (!rtb::invert_camera(*cam, dc, err)) return fail(RT_E_INVALID, err);
+    {
+        std::string err;
+        if (!rtb::invert_camera(*cam, dc, err)) return fail(RT_E_INVALID, err);
+    }
     if (rp.n_local_tiles == 0) return RT_OK;
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
     DCamera* d_cam;
-    if (g.cam_last_slot >= 0 && std::memcmp(&g.cam_last, cam, sizeof(rt_camera)) == 0) d_cam = g.cam_ring + g.cam_last_slot;
-    else {
-        /* a new camera goes to the next ring slot (never the one an earlier launch may still read);
-         * the copy source is pageable, so it is staged before the call returns */
-        g.cam_last_slot = (int)(g.cam_next++ % kCamSlots);
-        d_cam = g.cam_ring + g.cam_last_slot;
+    int cam_slot = -1, order_slot = -1;
+    if (g.cam_last_slot >= 0 && g.cam_last_stream == hip_stream && std::memcmp(&g.cam_last, cam, sizeof(rt_camera)) == 0) {
+        cam_slot = g.cam_last_slot; /* uploaded earlier on this very stream: ordered before anything enqueued now */
+        d_cam = g.cam_ring + cam_slot;
+    } else {
+        /* a new camera goes to the next ring slot; a launch of another stream that may still read that slot is waited for.
+         * The copy source is pageable, so it is staged before the call returns. */
+        cam_slot = (int)(g.cam_next++ % kCamSlots);
+        d_cam = g.cam_ring + cam_slot;
+        if (g.cam_used[cam_slot] && g.cam_stream[cam_slot] != hip_stream) HIP_TRY(hipStreamWaitEvent(st, g.cam_done[cam_slot], 0));
+        g.cam_last_slot = -1; /* until the copy is known to be enqueued */
         HIP_TRY(hipMemcpyAsync(d_cam, &dc, sizeof(DCamera), hipMemcpyHostToDevice, st));
-        g.cam_last = *cam;
+        g.cam_last = *cam; g.cam_last_slot = cam_slot; g.cam_last_stream = hip_stream;
     }
     const uint32_t* d_order = nullptr;
     /* Without bounces every tree has one node: nothing to order.  With a triangle BVH in the scene the probe has to
      * traverse it for every pixel (3.9 ms of a 29 ms frame on 10 M triangles) and the order it finds gains nothing:
      * there the long waves are the ones whose shadow rays skim the mesh, which the probe does not see. */
     if (g.order_tiles && r->has_bounce && !(r->mode & RT_M_BVH) && rp.n_local_tiles > 1) {
-        Lib::OrderKey key;
-        std::memset(&key, 0, sizeof(key));
-        key.scene = scene; key.stream = hip_stream; key.cam = *cam; key.w = w; key.h = h; key.tile_w = tile_w; key.tile_h = tile_h; key.rank = rank; key.world = world;
-        if (sample0 > 0 && g.order_last_slot >= 0 && std::memcmp(&key, &g.order_key, sizeof(key)) == 0) {
-            d_order = g.order_ws[g.order_last_slot] + rp.n_local_tiles;
-        } else {
-            const unsigned slot = g.order_next++ % kOrderSlots;
-            const size_t words = 2 * (size_t)rp.n_local_tiles;
-            if (g.order_cap[slot] < words) {
-                /* hipFree waits for the device, so no launch still reads the old block */
-                if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
-                HIP_TRY(hipMalloc((void**)&g.order_ws[slot], words * 4));
-                g.order_cap[slot] = words;
+        uint32_t* ws = nullptr;
+        {
+            Lib::OrderKey key;
+            std::memset(&key, 0, sizeof(key));
+            key.scene = scene; key.stream = hip_stream; key.cam = *cam; key.w = w; key.h = h; key.tile_w = tile_w; key.tile_h = tile_h; key.rank = rank; key.world = world;
+            if (sample0 > 0 && g.order_last_slot >= 0 && std::memcmp(&key, &g.order_key, sizeof(key)) == 0) {
+                order_slot = g.order_last_slot; /* same stream as the probe that filled it */
+                d_order = g.order_ws[order_slot] + rp.n_local_tiles;
+            } else {
+                const unsigned slot = g.order_next++ % kOrderSlots;
+                const size_t words = 2 * (size_t)rp.n_local_tiles;
+                if (g.order_used[slot] && g.order_stream[slot] != hip_stream) HIP_TRY(hipStreamWaitEvent(st, g.order_done[slot], 0));
+                if (g.order_cap[slot] < words) {
+                    /* hipFree waits for the device, so no launch still reads the old block */
+                    if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
+                    HIP_TRY(hipMalloc((void**)&g.order_ws[slot], words * 4));
+                    g.order_cap[slot] = words;
+                }
+                ws = g.order_ws[slot];
+                g.order_key = key;
+                g.order_last_slot = order_slot = (int)slot;
             }
-            uint32_t* ws = g.order_ws[slot];
+        }
+        if (ws) {
             RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws);
             hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
             HIP_TRY(hipGetLastError());
             d_order = ws + rp.n_local_tiles;
-            g.order_key = key;
-            g.order_last_slot = (int)slot;
         }
     }
     /* The samples of the call are cut so that every launch fills its waves: whole 64-sample chunks go to the
@@ -1020,7 +1063,17 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
         HIP_TRY(hipGetLastError());
         s0 += n; left -= n;
     }
+    /* the ring slots this call read are busy until here */
+    if (cam_slot >= 0) { HIP_TRY(hipEventRecord(g.cam_done[cam_slot], st)); g.cam_used[cam_slot] = true; g.cam_stream[cam_slot] = hip_stream; }
+    if (order_slot >= 0) { HIP_TRY(hipEventRecord(g.order_done[order_slot], st)); g.order_used[order_slot] = true; g.order_stream[order_slot] = hip_stream; }
     return RT_OK;
+}
+
+int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass, uint32_t sample0,
+                          uint32_t spp_total, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
+                          float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
+    return render_pass(scene, cam, w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank, world, d_rgb_tiles,
+                       d_counters, hip_stream);
 }
 
 int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
@@ -1040,7 +1093,7 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
     if ((rc = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, rank, world, (float*)d_out, (uint64_t*)d_cnt, g.stream))) return rc;
     HIP_TRY(hipEventRecord(g.ev1, g.stream));
     std::vector<uint64_t> slots(RT_COUNTER_WORDS);
-    uint64_t cnt[5];
+    uint64_t cnt[RT_COUNTER_FIELDS];
     if (bytes) HIP_TRY(hipMemcpyAsync(rgb_tiles, d_out, bytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -1049,7 +1102,7 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
-        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4];
+        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4]; stats->rays_skipped = cnt[5];
     }
     return RT_OK;
 }

@@ -123,6 +123,8 @@ RT_DEV T ldc(const T* p) {
 /* per-lane context: work counters (summed per workgroup at the end) and the base of this lane's
  * slice of the LDS traversal stack (element i lives at stack[i * stack_stride]) */
 struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris; /* BVH nodes fetched, triangles tested */
+             float* frames; uint32_t frame_stride; /* LDS part of the path-frame stack (trace_path), may be null when unused */
+             uint32_t skipped; /* of `rays`: shadow queries the reference issues but whose result it discards (skip_shade) */
              uint32_t stack_stride; /* threads of the workgroup: element i of the lane's stack lives at stack[i * stack_stride] */ };
 /* kernel variants: bit 0 = the object kd-tree has internal nodes, bit 1 = some mesh has a triangle BVH.
  * Code a scene cannot reach is compiled out of its variant, which keeps the common variant's registers low. */
@@ -907,23 +909,71 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     return (ambient + diffuse) + specular;
 }
 
+/* Scene::phong for a node whose colour the reference never uses: a glass sphere hit with bounces left
+ * (R/src/Scene.h:626 computes it, :705 overwrites it with F * reflected + (1 - F) * refracted).  Only what the
+ * rest of the sample can observe is kept: the position in the random stream (32 draws per quad light,
+ * R/src/Scene.h:369-370 via :259-260; none for a point light) and the work counters, which keep counting what
+ * the reference does -- the shadow queries not traced are reported separately in `skipped`. */
+RT_DEV void skip_shade(const DeviceScene& sc, Rng& rng, Cnt& cnt) {
+    ++cnt.nodes;
+    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+        const uint32_t n = ldc(&sc.lights[li].type) == RT_LIGHT_QUAD ? 16u : 1u;
+        if (n == 16u) rng.k += 32u;
+        cnt.rays += n;
+        cnt.skipped += n;
+    }
+}
+
 /* ---- Scene::rayTraceRecursive, R/src/Scene.h:596-713, as a loop --------------------------
  * The recursion (depth <= 11, reflected child before refracted child) becomes a loop over
  * "calls" with a small per-lane frame stack; the colour arithmetic on the way back up is the
  * reference's, in the reference's order, so the result does not depend on the rewrite.
- * frame layout (8 floats): kind, F, a[3], b[3]
- *   kind 1 mirror : a = phong colour of the node, b = specular_material
- *   kind 2 glass, reflected child running : a = refracted origin, b = refracted direction
- *   kind 3 glass, reflected child running, no refracted ray (total internal reflection)
- *   kind 4 glass, refracted child running : a = reflected colour
+ * A frame is RT_FRAME_WORDS words; what kind it is lives in two bits per level of one register:
+ *   kind 0 mirror : w0..2 = phong colour of the node, w3 = material index (specular_material is read again)
+ *   kind 1 glass, reflected child running : w0..2 = refracted origin, w3..5 = refracted direction, w6 = F
+ *   kind 2 glass, reflected child running, no refracted ray (total internal reflection): w6 = F
+ *   kind 3 glass, refracted child running : w0..2 = reflected colour, w6 = F
+ * The first L levels of the stack live in LDS (word w of level l of this lane at cnt.frames[(l * RT_FRAME_WORDS
+ * + w) * cnt.frame_stride]: lane-interleaved, conflict-free), deeper ones in a per-lane array.  A per-lane array
+ * indexed by the stack pointer is scratch memory: every push and pop of it is a round trip through the memory
+ * hierarchy, 64 lanes wide, and most path trees are shallow.
  * PROBE = true walks the same tree without shading it (no light samples, no shadow rays) and only
  * counts its nodes in cnt.nodes, up to RT_PROBE_CAP: the tree's shape does not depend on the shading. */
 #define RT_MAX_BOUNCES 10
 #define RT_PROBE_CAP 24
-template <int M, bool PROBE = false>
+#define RT_FRAME_WORDS 7
+template <int L>
+struct FrameStack {
+    float* lds; uint32_t stride;
+    float deep[(RT_MAX_BOUNCES - L > 0 ? RT_MAX_BOUNCES - L : 1) * RT_FRAME_WORDS];
+    /* N words of level l, from / into v[first .. first + N) */
+    template <int FIRST, int N>
+    RT_DEV void put(int l, const float (&v)[RT_FRAME_WORDS]) {
+        if (L >= RT_MAX_BOUNCES || l < L) {
+#pragma unroll
+            for (int w = FIRST; w < FIRST + N; ++w) lds[(uint32_t)(l * RT_FRAME_WORDS + w) * stride] = v[w];
+        } else {
+#pragma unroll
+            for (int w = FIRST; w < FIRST + N; ++w) deep[(l - L) * RT_FRAME_WORDS + w] = v[w];
+        }
+    }
+    template <int FIRST, int N>
+    RT_DEV void get(int l, float (&v)[RT_FRAME_WORDS]) const {
+        if (L >= RT_MAX_BOUNCES || l < L) {
+#pragma unroll
+            for (int w = FIRST; w < FIRST + N; ++w) v[w] = lds[(uint32_t)(l * RT_FRAME_WORDS + w) * stride];
+        } else {
+#pragma unroll
+            for (int w = FIRST; w < FIRST + N; ++w) v[w] = deep[(l - L) * RT_FRAME_WORDS + w];
+        }
+    }
+};
+template <int M, bool PROBE = false, int L = 0>
 RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
-    float stk[RT_MAX_BOUNCES][8];
+    FrameStack<L> stk;
+    stk.lds = cnt.frames; stk.stride = cnt.frame_stride;
     int sp = 0;
+    uint32_t kinds = 0; /* bits 2 l, 2 l + 1: kind of the frame at level l */
     f3 ret = mk3(0.f, 0.f, 0.f);
     for (;;) {
         HitRec rec = closest_rec<M>(sc, o, d, cnt);
@@ -932,20 +982,26 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
         else {
             FullHit h = finish_hit(sc, rec, o, d);
             f3 col = mk3(0.f, 0.f, 0.f);
+            const bool bounces = sp < RT_MAX_BOUNCES && h.type == RT_SPHERE;
+            int mat = 0, mtype = RT_MAT_DIFFUSE;
+            if (bounces) { mat = ldc(&sc.spheres[h.obj].mat); mtype = ldc(&sc.materials[mat].type); }
             if (PROBE) { if (++cnt.nodes >= RT_PROBE_CAP) return ret; }
+            else if (mtype == RT_MAT_GLASS) skip_shade(sc, rng, cnt);
             else col = shade<M>(sc, h, rng, cnt);
             ret = col;
-            if (sp < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
-                const DMaterial m = ldc(&sc.materials[ldc(&sc.spheres[h.obj].mat)]);
+            if (bounces && mtype != RT_MAT_DIFFUSE) {
                 f3 P = h.p, N = h.n, I = d;
-                if (m.type == RT_MAT_MIRROR) {
+                float f[RT_FRAME_WORDS];
+                if (mtype == RT_MAT_MIRROR) {
                     f3 R = I - (2.0f * dot3(I, N)) * N;
-                    float* f = stk[sp++];
-                    f[0] = 1.f; f[1] = 0.f; f[2] = col.x; f[3] = col.y; f[4] = col.z; f[5] = m.ks[0]; f[6] = m.ks[1]; f[7] = m.ks[2];
+                    f[0] = col.x; f[1] = col.y; f[2] = col.z; f[3] = __int_as_float(mat);
+                    stk.template put<0, 4>(sp, f);
+                    kinds &= ~(3u << (2 * sp));
+                    ++sp;
                     o = P + 0.001f * N; d = norm3_unit(R);
                     descended = true;
-                } else if (m.type == RT_MAT_GLASS) {
-                    float n1 = 1.0f, n2 = m.ior;
+                } else if (mtype == RT_MAT_GLASS) {
+                    float n1 = 1.0f, n2 = ldc(&sc.materials[mat].ior);
                     if (dot3(I, N) > 0.0f) { float s = n1; n1 = n2; n2 = s; N = -1.0f * N; }
                     float cosI = __builtin_fabsf(dot3(I, N));
                     float eta = n1 / n2;
@@ -960,13 +1016,20 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
                         F = (rs * rs + rp * rp) / 2.0f;
                     }
                     f3 R = I - (2.0f * dot3(I, N)) * N;
-                    float* f = stk[sp++];
-                    f[1] = F;
+                    f[6] = F;
+                    uint32_t kind;
                     if (F < 1.0f) {
                         f3 T = eta * (I - cosI * N) - __builtin_sqrtf(1.0f - sinT2) * N;
                         f3 to = P - 0.001f * N, td = norm3_unit(T);
-                        f[0] = 2.f; f[2] = to.x; f[3] = to.y; f[4] = to.z; f[5] = td.x; f[6] = td.y; f[7] = td.z;
-                    } else f[0] = 3.f;
+                        f[0] = to.x; f[1] = to.y; f[2] = to.z; f[3] = td.x; f[4] = td.y; f[5] = td.z;
+                        stk.template put<0, 7>(sp, f);
+                        kind = 1u;
+                    } else {
+                        stk.template put<6, 1>(sp, f);
+                        kind = 2u;
+                    }
+                    kinds = (kinds & ~(3u << (2 * sp))) | (kind << (2 * sp));
+                    ++sp;
                     o = P + 0.001f * N; d = norm3_unit(R);
                     descended = true;
                 }
@@ -975,21 +1038,30 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
         if (descended) continue;
         bool resumed = false;
         while (sp > 0) {
-            float* f = stk[sp - 1];
-            int kind = (int)f[0];
-            if (kind == 1) {
-                ret = mk3(f[2] + ret.x * f[5], f[3] + ret.y * f[6], f[4] + ret.z * f[7]);
+            const int l = sp - 1;
+            const uint32_t kind = (kinds >> (2 * l)) & 3u;
+            float f[RT_FRAME_WORDS];
+            if (kind == 0u) {
+                stk.template get<0, 4>(l, f);
+                const f3 ks = ld3c(sc.materials[__float_as_int(f[3])].ks);
+                ret = mk3(f[0] + ret.x * ks.x, f[1] + ret.y * ks.y, f[2] + ret.z * ks.z);
                 --sp;
-            } else if (kind == 2) {
-                o = mk3(f[2], f[3], f[4]); d = mk3(f[5], f[6], f[7]);
-                f[0] = 4.f; f[2] = ret.x; f[3] = ret.y; f[4] = ret.z;
+            } else if (kind == 1u) {
+                stk.template get<0, 6>(l, f);
+                o = mk3(f[0], f[1], f[2]); d = mk3(f[3], f[4], f[5]);
+                f[0] = ret.x; f[1] = ret.y; f[2] = ret.z;
+                stk.template put<0, 3>(l, f);
+                kinds |= 3u << (2 * l);
                 resumed = true;
                 break;
-            } else if (kind == 3) {
-                ret = f[1] * ret + (1.0f - f[1]) * mk3(0.f, 0.f, 0.f);
+            } else if (kind == 2u) {
+                stk.template get<6, 1>(l, f);
+                ret = f[6] * ret + (1.0f - f[6]) * mk3(0.f, 0.f, 0.f);
                 --sp;
             } else {
-                ret = f[1] * mk3(f[2], f[3], f[4]) + (1.0f - f[1]) * ret;
+                stk.template get<0, 3>(l, f);
+                stk.template get<6, 1>(l, f);
+                ret = f[6] * mk3(f[0], f[1], f[2]) + (1.0f - f[6]) * ret;
                 --sp;
             }
         }
