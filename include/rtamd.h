@@ -306,6 +306,20 @@ int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, ui
                           uint32_t spp_pass, uint32_t sample0, uint32_t spp_total, uint32_t seed,
                           uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
                           float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
+/* rt_render_device for callers that cannot allocate device memory while they run (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments,
+ * same tile-major output and same floats as rt_render_device, but the call allocates nothing -- no hipMalloc /
+ * hipFree, no host-heap allocation on the success path: the inverted camera (passed to the device as a kernel
+ * argument) and the workspace of the tile launch order live in one static array in device memory of
+ * 512 B + 8 B x RT_NOALLOC_MAX_TILES = 1 MiB + 512 B, which every GPU the library runs on holds until the process
+ * ends.  A rank's share of more than RT_NOALLOC_MAX_TILES tiles is refused with RT_E_LIMIT (3840 x 2160 in 16 x 16
+ * tiles is 32 400).  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, or
+ * two threads) race on it; calls on one stream are ordered by the stream.  Nothing in the array has to start at
+ * zero -- each call rewrites what it reads. */
+#define RT_NOALLOC_MAX_TILES (1u << 17)
+int rt_render_device_noalloc(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp,
+                             uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
+                             float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream);
 /* d_counters: NULL, or a zeroed device buffer of RT_COUNTER_WORDS uint64 (see above).  Host helper:
  * totals {rays, samples, nodes, bvh_nodes, bvh_tris, rays_skipped} of a counter buffer copied back to the host. */
 void rt_counters_total(const uint64_t* h_counters, uint64_t out[RT_COUNTER_FIELDS]);

@@ -81,7 +81,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
 # every symbol include/rtamd.h declares
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
-           "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
+           "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_render_device_noalloc", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
 _lib = None
 
@@ -112,6 +112,7 @@ def lib():
         L.rt_tiles_per_rank.argtypes = [u32] * 6
         L.rt_render.argtypes = [u64, C.POINTER(Camera)] + [u32] * 8 + [vp, C.POINTER(Stats)]
         L.rt_render_device.argtypes = [u64, C.POINTER(Camera)] + [u32] * 8 + [vp, vp, vp]
+        L.rt_render_device_noalloc.argtypes = [u64, C.POINTER(Camera)] + [u32] * 8 + [vp, vp, vp]
         L.rt_render_pass_device.argtypes = [u64, C.POINTER(Camera)] + [u32] * 10 + [vp, vp, vp]
         L.rt_tiles_to_image.argtypes = [vp, u32, u32, u32, u32, u32, vp]
         L.rt_tiles_to_rgb8_device.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp]
@@ -237,6 +238,12 @@ class DeviceScene:
         check(lib().rt_render_device(self.h, C.byref(cam), w, h, spp, seed, tile_w, tile_h, rank, world,
                                      C.c_void_p(d_out_ptr), C.c_void_p(d_counters_ptr), C.c_void_p(stream_ptr)))
 
+
+    def render_device_noalloc(self, cam, w, h, spp, seed, tile_w, tile_h, rank, world, d_out_ptr, d_counters_ptr, stream_ptr):
+        """rt_render_device_noalloc: same result as render_device, allocates nothing (static device array)."""
+        cam = cam if isinstance(cam, Camera) else copy_struct(Camera, cam)
+        check(lib().rt_render_device_noalloc(self.h, C.byref(cam), w, h, spp, seed, tile_w, tile_h, rank, world,
+                                             C.c_void_p(d_out_ptr), C.c_void_p(d_counters_ptr), C.c_void_p(stream_ptr)))
 
     def render_pass_device(self, cam, w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank, world, d_out_ptr,
                            d_counters_ptr, stream_ptr):

@@ -333,6 +333,20 @@ __global__ __launch_bounds__(256) void k_generate(DCamera cam, const float* __re
     dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
 }
 
+/* ---- device memory of rt_render_device_noalloc ----------------------------------------------
+ * That entry point may not allocate, so what a render needs besides the caller's buffers -- the inverted camera
+ * and the workspace of the tile launch order -- lives in this array, which every GPU the library runs on holds
+ * for the life of the process.  Host code never uses the array's name as an address: rt_init asks the runtime
+ * for the array's address on the current device (hipGetSymbolAddress) and everything goes through that pointer. */
+#define RT_NOALLOC_CAM_BYTES 512u
+static_assert(sizeof(DCamera) <= RT_NOALLOC_CAM_BYTES, "camera slot of the static scratch array");
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_CAM_BYTES + 2ull * RT_NOALLOC_MAX_TILES * sizeof(uint32_t)];
+
+/* the inverted camera travels as a kernel argument: no host-to-device copy has to be staged */
+__global__ __launch_bounds__(64) void k_put_camera(DCamera cam, DCamera* __restrict__ dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = cam;
+}
+
 /* normalisation through the shortened sequences vs through the IEEE operators, on random vectors */
 __global__ __launch_bounds__(256) void k_selftest_arith(uint64_t n, uint32_t seed, unsigned long long* mismatches) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,6 +454,7 @@ struct Lib {
     hipEvent_t cam_done[kCamSlots] = {}, order_done[kOrderSlots] = {};
     void* cam_stream[kCamSlots] = {}; void* order_stream[kOrderSlots] = {};
     bool cam_used[kCamSlots] = {}, order_used[kOrderSlots] = {};
+    unsigned char* scratch_ptr = nullptr; /* address of the static `scratch` array on this device */
     /* the launch order of the latest probe and what it was made for: the later passes of a progressive render
      * (sample0 > 0, same stream, everything else unchanged) use it again instead of probing the same path trees once more */
     struct OrderKey { rt_scene_t scene; void* stream; rt_camera cam; uint32_t w, h, tile_w, tile_h, rank, world; };
@@ -632,6 +647,9 @@ int rt_init(int device) {
     HIP_TRY(hipMalloc((void**)&g.cam_ring, kCamSlots * sizeof(DCamera)));
     for (unsigned i = 0; i < kCamSlots; ++i) { HIP_TRY(hipEventCreateWithFlags(&g.cam_done[i], hipEventDisableTiming)); g.cam_used[i] = false; }
     for (unsigned i = 0; i < kOrderSlots; ++i) { HIP_TRY(hipEventCreateWithFlags(&g.order_done[i], hipEventDisableTiming)); g.order_used[i] = false; }
+    /* this device's copy of the static array (each GPU holds its own, at its own address) */
+    g.scratch_ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&g.scratch_ptr, HIP_SYMBOL(scratch)));
     g.cam_next = 0;
     g.cam_last_slot = -1;
     const char* ord = std::getenv("RTAMD_TILE_ORDER");
@@ -653,6 +671,7 @@ int rt_shutdown(void) {
     g.order_last_slot = -1;
     for (unsigned i = 0; i < kCamSlots; ++i) if (g.cam_done[i]) { (void)hipEventDestroy(g.cam_done[i]); g.cam_done[i] = nullptr; }
     for (unsigned i = 0; i < kOrderSlots; ++i) if (g.order_done[i]) { (void)hipEventDestroy(g.order_done[i]); g.order_done[i] = nullptr; }
+    g.scratch_ptr = nullptr;
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
@@ -975,9 +994,10 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
     return rt_render_pass_device(scene, cam, w, h, spp, 0, spp, seed, tile_w, tile_h, rank, world, d_rgb_tiles, d_counters, hip_stream);
 }
 
-/* One pass of a render, enqueued on `st`: the camera goes to the next slot of the camera ring and the launch order to the
- * next workspace of the order ring. */
-static int render_pass(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass,
+/* One pass of a render, enqueued on `st`.  static_mem = false: the camera goes to the next slot of the camera ring and the
+ * launch order to the next workspace of the order ring (library allocations).  static_mem = true: both live in the static
+ * `scratch` array of this device and nothing is allocated, on the device or on the host heap. */
+static int render_pass(bool static_mem, rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass,
                        uint32_t sample0, uint32_t spp_total, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
                        float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_render: call rt_init first");
@@ -990,6 +1010,8 @@ static int render_pass(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint3
     int rc = make_render_params(w, h, spp, seed, tile_w, tile_h, rank, world, rp);
     if (rc) return rc;
     rp.sample0 = sample0; rp.spp_total = spp_total;
+    if (static_mem && rp.n_local_tiles > RT_NOALLOC_MAX_TILES)
+        return fail(RT_E_LIMIT, "rt_render_device_noalloc: more than RT_NOALLOC_MAX_TILES (131072) tiles in this rank's share; use larger tiles or rt_render_device");
     DCamera dc;
     {
         std::string err;
@@ -999,7 +1021,11 @@ static int render_pass(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint3
     hipStream_t st = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
     DCamera* d_cam;
     int cam_slot = -1, order_slot = -1;
-    if (g.cam_last_slot >= 0 && g.cam_last_stream == hip_stream && std::memcmp(&g.cam_last, cam, sizeof(rt_camera)) == 0) {
+    if (static_mem) {
+        d_cam = (DCamera*)g.scratch_ptr;
+        hipLaunchKernelGGL(k_put_camera, dim3(1), dim3(64), 0, st, dc, d_cam);
+        HIP_TRY(hipGetLastError());
+    } else if (g.cam_last_slot >= 0 && g.cam_last_stream == hip_stream && std::memcmp(&g.cam_last, cam, sizeof(rt_camera)) == 0) {
         cam_slot = g.cam_last_slot; /* uploaded earlier on this very stream: ordered before anything enqueued now */
         d_cam = g.cam_ring + cam_slot;
     } else {
@@ -1018,7 +1044,8 @@ static int render_pass(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint3
      * there the long waves are the ones whose shadow rays skim the mesh, which the probe does not see. */
     if (g.order_tiles && r->has_bounce && !(r->mode & RT_M_BVH) && rp.n_local_tiles > 1) {
         uint32_t* ws = nullptr;
-        {
+        if (static_mem) ws = (uint32_t*)(g.scratch_ptr + RT_NOALLOC_CAM_BYTES);
+        else {
             Lib::OrderKey key;
             std::memset(&key, 0, sizeof(key));
             key.scene = scene; key.stream = hip_stream; key.cam = *cam; key.w = w; key.h = h; key.tile_w = tile_w; key.tile_h = tile_h; key.rank = rank; key.world = world;
@@ -1072,8 +1099,14 @@ static int render_pass(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint3
 int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp_pass, uint32_t sample0,
                           uint32_t spp_total, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
                           float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
-    return render_pass(scene, cam, w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank, world, d_rgb_tiles,
+    return render_pass(false, scene, cam, w, h, spp_pass, sample0, spp_total, seed, tile_w, tile_h, rank, world, d_rgb_tiles,
                        d_counters, hip_stream);
+}
+
+int rt_render_device_noalloc(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
+                             uint32_t tile_h, uint32_t rank, uint32_t world, float* d_rgb_tiles, uint64_t* d_counters, void* hip_stream) {
+    return render_pass(true, scene, cam, w, h, spp, 0, spp, seed, tile_w, tile_h, rank, world, d_rgb_tiles, d_counters,
+                       hip_stream);
 }
 
 int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
