@@ -101,6 +101,9 @@ def lib():
         L.orc_generate_rays.argtypes = [C.POINTER(Camera), vp, vp, C.c_size_t, vp, vp]
         L.orc_normalize_dirs.argtypes = [vp, C.c_size_t, vp]
         L.orc_intersect.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.orc_intersect_mt.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int]
+        L.orc_render_pixels.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t,
+                                        C.c_int, vp, C.POINTER(Stats)]
         L.orc_mesh_intersect.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, vp]
         L.orc_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(Stats)]
         L.orc_render.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
@@ -161,12 +164,23 @@ class Scene:
                                box.ctypes.data_as(C.POINTER(C.c_float)))
         return nodes, refs, box
 
-    def intersect(self, org, dirs):
+    def intersect(self, org, dirs, threads=1):
         org, dirs = _f32(org), _f32(dirs)
         n = org.shape[0]
         out = np.zeros(n, HIT_DTYPE)
-        lib().orc_intersect(self.h, _ptr(org), _ptr(dirs), n, _ptr(out))
+        if threads > 1:
+            lib().orc_intersect_mt(self.h, _ptr(org), _ptr(dirs), n, _ptr(out), threads)
+        else:
+            lib().orc_intersect(self.h, _ptr(org), _ptr(dirs), n, _ptr(out))
         return out
+
+    def render_pixels(self, cam, w, h, spp, pixels, seed=1, threads=1):
+        """Colours of the listed pixels (x + y * w) of a w x h render under the counter RNG: (n, 3) float32, Stats."""
+        pixels = np.ascontiguousarray(pixels, np.uint32)
+        rgb = np.zeros((len(pixels), 3), np.float32)
+        st = Stats()
+        lib().orc_render_pixels(self.h, C.byref(cam), w, h, spp, seed, _ptr(pixels), len(pixels), threads, _ptr(rgb), C.byref(st))
+        return rgb, st
 
     def mesh_intersect(self, mesh, org, dirs):
         org, dirs = _f32(org), _f32(dirs)

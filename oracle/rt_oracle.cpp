@@ -984,6 +984,27 @@ void orc_intersect(orc_scene* h, const float* org, const float* dir, size_t n, r
     h->total += c;
 }
 
+/* The same over `threads` workers (rays are independent): for scenes whose brute-force Mesh::intersect loop makes a
+ * few thousand rays cost 10^9 triangle tests. */
+void orc_intersect_mt(orc_scene* h, const float* org, const float* dir, size_t n, rt_hit* out, int threads) {
+    if (threads < 1) threads = 1;
+    std::vector<Counters> cs(threads);
+    std::atomic<size_t> next(0);
+    auto work = [&](int tid) {
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            Ray r = Ray::stored(from3(org + 3 * i), from3(dir + 3 * i));
+            fill_hit(out[i], closest_hit(h->s, r, cs[tid]));
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
+    for (const Counters& x : cs) h->total += x;
+}
+
 void orc_mesh_intersect(orc_scene* h, uint32_t mesh, const float* org, const float* dir, size_t n, rt_hit* out) {
     Counters c;
     for (size_t i = 0; i < n; ++i) {
@@ -1052,6 +1073,49 @@ void orc_render(orc_scene* h, const rt_camera* cam, uint32_t w, uint32_t hgt, ui
         for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
         for (auto& t : pool) t.join();
     }
+    Counters c;
+    for (const Counters& x : cs) c += x;
+    h->total += c;
+    if (stats) { stats->rays = c.rays; stats->samples = c.samples; stats->nodes = c.nodes; stats->kernel_ms = 0; stats->bvh_nodes = 0; stats->bvh_tris = 0; stats->rays_skipped = 0; }
+}
+
+/* The pixel loop body of ray_trace_from_camera (R/main.cpp:185-193) for a list of pixels (x + y * w) of a w x hgt
+ * image under the counter RNG: rgb gets 3 floats per listed pixel.  For frames whose full rows are out of reach of
+ * the brute-force triangle loop. */
+void orc_render_pixels(orc_scene* h, const rt_camera* cam, uint32_t w, uint32_t hgt, uint32_t spp, uint32_t seed,
+                       const uint32_t* pixels, size_t n, int threads, float* rgb, rt_stats* stats) {
+    const OScene& s = h->s;
+    CamInv ci = invert_camera(*cam);
+    if (threads < 1) threads = 1;
+    std::vector<Counters> cs(threads);
+    std::atomic<size_t> next(0);
+    auto work = [&](int tid) {
+        Counters& c = cs[tid];
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            const uint32_t x = pixels[i] % w, y = pixels[i] / w;
+            V3 acc;
+            for (uint32_t sidx = 0; sidx < spp; ++sidx) {
+                Rng rng;
+                rng.mode = RT_RNG_COUNTER;
+                rng.key = rt_rng_key(seed, x + y * w, sidx);
+                float u = ((float)(int)x + rng.unit()) / (int)w;
+                float v = ((float)(int)y + rng.unit()) / (int)hgt;
+                V3 o, d;
+                primary_ray(ci, u, v, o, d);
+                V3 col = trace(s, Ray(o, d), 10, rng, c);
+                ++c.samples;
+                acc = add(acc, col);
+            }
+            acc = divs(acc, (float)spp);
+            for (int a = 0; a < 3; ++a) rgb[3 * i + a] = acc[a];
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
     Counters c;
     for (const Counters& x : cs) c += x;
     h->total += c;
