@@ -188,6 +188,14 @@ int rt_init(int device);
 int rt_shutdown(void);
 const char* rt_last_error(void);
 
+/* Scheduling switches of the render calls; none of them changes a result (GPU tests compare the floats).  No
+ * reference counterpart.  Each also has an environment variable read by rt_init.
+ *   "tile_order" 0 / 1 (RTAMD_TILE_ORDER): launch the tiles deepest-path-first (default 1) or in index order
+ *   "wide"       0 / 1 (RTAMD_WIDE): render the pixels with deep path trees with several lanes per path (default 1)
+ *   "wide_nodes" 1 .. 24 (RTAMD_WIDE_NODES): a pixel counts as deep when the path tree of its centre ray has at least
+ *                this many nodes (default 24) */
+int rt_set_option(const char* name, int64_t value);
+
 /* Device self-test of the library's shortened divide / sqrt sequences: normalises `n` pseudo-random
  * vectors (components with random signs, mantissas and exponents in [2^-44, 2^44], i.e. across and
  * beyond the range the fast path accepts) both ways and counts results whose bits differ from the

@@ -79,7 +79,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
                       ("n", "<f4", 3), ("pad2", "<f4")])
 
 # every symbol include/rtamd.h declares
-EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_destroy", "rt_scene_kdtree",
+EXPORTS = ["rt_init", "rt_set_option", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
            "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_render_device_noalloc", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
@@ -97,6 +97,7 @@ def lib():
         vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
         L.rt_last_error.restype = C.c_char_p
         L.rt_init.argtypes = [C.c_int]
+        L.rt_set_option.argtypes = [C.c_char_p, C.c_int64]
         L.rt_scene_check.argtypes = [C.POINTER(SceneDesc), C.POINTER(BuildInfo)]
         L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(u64)]
         L.rt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), u32, C.POINTER(u64)]
@@ -130,6 +131,11 @@ def check(rc):
 
 def init(device=0):
     check(lib().rt_init(device))
+
+
+def set_option(name, value):
+    """rt_set_option: scheduling switches ("tile_order", "wide", "wide_nodes"); results never depend on them."""
+    check(lib().rt_set_option(name.encode(), int(value)))
 
 
 def shutdown():

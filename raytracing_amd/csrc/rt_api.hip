@@ -17,6 +17,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -39,6 +40,18 @@ struct RenderParams {
     uint32_t tile_w, tile_h, tiles_x, n_tiles;
     uint32_t rank, world, n_local_tiles, sample0; /* first sample of this pass */
     uint32_t spp_total, pad[3];                   /* samples per pixel of the finished image */
+};
+
+/* Work list of the pixels whose path trees are deep: k_tile_class fills it, k_render skips the listed pixels,
+ * k_render_wide traces them with several lanes per path and k_resolve_deep adds their samples up.  All pointers null = off. */
+struct DeepList {
+    uint32_t* head;     /* [0] pixels appended (may run past cap: readers clamp), [1] next item of k_render_wide's queue */
+    uint32_t* pixels;   /* cap entries: index of the pixel in the rank's tile buffer = local_tile * pixels per tile + position in tile */
+    uint8_t* flags;     /* per pixel of the tile buffer: 1 = listed */
+    float* colors;      /* cap x spp of the pass x 3: the colour of every sample of the listed pixels */
+    uint32_t* tree;     /* n_workers x RT_TREE_NODES x RT_TREE_WORDS: the path trees a worker wave is expanding */
+    uint32_t cap, min_nodes; /* a pixel is listed when the probe of its centre ray counts at least min_nodes path nodes */
+    uint32_t n_workers, pad;
 };
 
 RT_DEV Cnt new_cnt(uint32_t* stack, uint32_t stack_stride, float* frames = nullptr, uint32_t frame_stride = 0) {
@@ -81,6 +94,9 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
  * wave is done, and next to a glass-rim pixel that takes 3 ms the three neighbours' slots would sit idle
  * (measured: 27.7 -> 27.2 ms on the full frame, 3.74 -> 3.61 ms on the slowest of eight ranks). */
 #define RT_RENDER_WAVES 1
+#if RT_RENDER_WAVES != 1
+#error "the worker workgroups of k_render are single waves"
+#endif
 #endif
 #ifndef RT_FRAME_LDS
 #define RT_FRAME_LDS 5 /* levels of the path-frame stack kept in LDS by the render variants without a BVH: 5 x 7 x 256 B = 8960 B per wave */
@@ -106,26 +122,46 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
  * Workspace (uint32): [0, n) key of local tile i (0 = deepest), [n, 2n) the order. */
 #define RT_ORDER_KEYS (RT_PROBE_CAP + 1)
 template <int M>
-__global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws) {
+__global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws, DeepList dl) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     __shared__ uint32_t s_deepest;
     const uint32_t local_tile = blockIdx.x; /* one workgroup per tile, one thread per pixel (a 16 x 16 tile) */
     const uint32_t tile = rp.rank + local_tile * rp.world;
     const uint32_t x0 = rt_tile_column(tile, rp.tiles_x) * rp.tile_w, y0 = (tile / rp.tiles_x) * rp.tile_h;
+    const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
     if (threadIdx.x == 0) s_deepest = 0;
     __syncthreads();
     uint32_t deepest = 0;
-    for (uint32_t i = threadIdx.x; i < rp.tile_w * rp.tile_h; i += 256) {
+    for (uint32_t i0 = 0; i0 < px_per_tile; i0 += 256) { /* every thread of the workgroup makes every trip */
+        const uint32_t i = i0 + threadIdx.x;
         const uint32_t x = x0 + i % rp.tile_w, y = y0 + i / rp.tile_w;
-        if (x >= rp.w || y >= rp.h) continue;
-        float u = ((float)(int)x + 0.5f) / (float)(int)rp.w;
-        float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
-        f3 o, d;
-        primary_ray(*cam, u, v, o, d);
-        Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
-        Rng rng; rng.key = 0; rng.k = 0;
-        (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
-        deepest = max(deepest, cnt.nodes);
+        const bool valid = i < px_per_tile && x < rp.w && y < rp.h;
+        uint32_t nodes = 0;
+        if (valid) {
+            float u = ((float)(int)x + 0.5f) / (float)(int)rp.w;
+            float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
+            f3 o, d;
+            primary_ray(*cam, u, v, o, d);
+            Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
+            Rng rng; rng.key = 0; rng.k = 0;
+            (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
+            nodes = cnt.nodes;
+            deepest = max(deepest, nodes);
+        }
+        if (dl.flags) { /* one atomic per wave reserves the list entries of its deep pixels */
+            const bool deep = valid && nodes >= dl.min_nodes;
+            const uint64_t mask = __ballot(deep);
+            uint32_t first = 0;
+            if (mask) {
+                const uint32_t lane = threadIdx.x & 63;
+                if (lane == (uint32_t)__builtin_ctzll(mask)) first = atomicAdd(&dl.head[0], (uint32_t)__popcll(mask));
+                first = (uint32_t)__shfl((int)first, (int)__builtin_ctzll(mask), 64);
+            }
+            const uint32_t entry = first + wave_rank(mask, threadIdx.x & 63);
+            const bool listed = deep && entry < dl.cap;
+            if (listed) dl.pixels[entry] = local_tile * px_per_tile + i;
+            if (i < px_per_tile) dl.flags[(uint64_t)local_tile * px_per_tile + i] = listed ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, off, 64));
@@ -153,6 +189,245 @@ __global__ __launch_bounds__(1024) void k_tile_place(uint32_t* __restrict__ ws, 
     for (uint32_t i = threadIdx.x; i < n; i += 1024) ws[n + atomicAdd(&s_cursor[ws[i]], 1u)] = i;
 }
 
+/* ---- path trees expanded level by level: the worker waves of k_render ------------------------------------------
+ * A pixel on the deep list has path trees of hundreds of nodes per sample (glass seen through glass).  Walked depth
+ * first by one lane per sample they are chains of hundreds of dependent closest-hit and shadow queries, and the wave
+ * that holds them is still running when the rest of the launch is done.  A worker wave instead expands the trees of up
+ * to RT_TREE_BATCH samples of such a pixel breadth first -- the recursion of R/src/Scene.h:596-713 has depth <= 11, so
+ * 11 rounds of closest-hit queries, one lane per node, find every node -- and then shades all nodes that need it side
+ * by side.  What the recursion's order decides is kept:
+ *   random numbers  a node that was hit draws 32 numbers per quad light (R/src/Scene.h:369-370), nodes in depth-first
+ *                   order, reflected subtree before refracted (R/src/Scene.h:694,701): node n's first draw is
+ *                   2 + Q * (number of hit nodes before n in that order), from subtree sizes added up level by level;
+ *   colours         combined upwards with the expressions of R/src/Scene.h:655,705, children first.
+ * Every value is computed by the routines trace_path uses (closest_rec, finish_hit, bounce_rays, shade), so a pixel
+ * gets the same floats whichever way it is rendered.  Children are appended to the next level with one ballot per
+ * chunk of 64 nodes.  Node fields live in this worker's slice of dl.tree (field f of node i at
+ * [f * RT_TREE_NODES + i]); a batch whose trees do not fit is cut in halves (one sample's tree has at most 2047 nodes).
+ * Workers take items (a listed pixel and a group of RT_TREE_BATCH of the pass's samples) from a counter until none is
+ * left; they are the first workgroups of the grid, so the long items start first. */
+#define RT_TREE_NODES 2048
+#define RT_TREE_WORDS 14
+#define RT_TREE_BATCH 16
+enum { TF_A0 = 0, TF_META = 6, TF_OBJ = 7, TF_F = 8, TF_C1 = 9, TF_C2 = 10, TF_SIZE = 11, TF_PRE = 12, TF_LIST = 13 };
+/* fields 0..5: the node's ray (origin, direction) until it is traced, then hit position and normal, then (0..2) its colour.
+ * meta = kind | hit type << 4 | sample of the batch << 8; kind 0 miss, 1 hit without children, 2 mirror, 3 glass with
+ * both children, 4 glass with the reflected child only */
+RT_DEV void tree_sync() { /* this wave's stores to the tree are visible to its later loads, whichever lane made them */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int M>
+RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, const RenderParams& rp, uint32_t* __restrict__ mem, uint32_t* s_lv,
+                       uint32_t x, uint32_t y, uint32_t s_first, uint32_t n_samples, uint32_t draws_per_node, float* __restrict__ colors, Cnt& cnt) {
+    const uint32_t lane = threadIdx.x & 63;
+    auto fld = [&](int f, uint32_t i) -> uint32_t& { return mem[(uint32_t)f * RT_TREE_NODES + i]; };
+    auto put3 = [&](int f, uint32_t i, f3 v) { fld(f, i) = __float_as_uint(v.x); fld(f + 1, i) = __float_as_uint(v.y); fld(f + 2, i) = __float_as_uint(v.z); };
+    auto get3 = [&](int f, uint32_t i) { return mk3(__uint_as_float(fld(f, i)), __uint_as_float(fld(f + 1, i)), __uint_as_float(fld(f + 2, i))); };
+    /* roots: R/main.cpp:186-190 */
+    if (lane < n_samples) {
+        Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, rp.sample0 + s_first + lane); rng.k = 0;
+        float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
+        float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
+        f3 o, d;
+        primary_ray(*cam, u, v, o, d);
+        put3(TF_A0, lane, o);
+        put3(TF_A0 + 3, lane, norm3_unit(d));
+        fld(TF_META, lane) = lane << 8;
+    }
+    tree_sync();
+    /* 1. expansion, one level per round */
+    uint32_t ls = 0, le = n_samples, depth = 0;
+    if (lane == 0) s_lv[0] = 0;
+    for (; ls < le; ++depth) {
+        uint32_t next = le;
+        for (uint32_t c = ls; c < le; c += 64) {
+            const uint32_t i = c + lane;
+            const bool active = i < le;
+            uint32_t nchild = 0, kind = 0, meta = 0, c1 = 0, c2 = 0;
+            Bounce bn;
+            bn.kind = 0; bn.F = 0.f;
+            bn.ro = bn.rd = bn.to = bn.td = mk3(0.f, 0.f, 0.f);
+            if (active) {
+                meta = fld(TF_META, i);
+                const f3 o = get3(TF_A0, i), d = get3(TF_A0 + 3, i);
+                HitRec rec = closest_rec<M>(sc, o, d, cnt);
+                if (rec.type >= 0) {
+                    FullHit h = finish_hit(sc, rec, o, d);
+                    put3(TF_A0, i, h.p);
+                    put3(TF_A0 + 3, i, h.n);
+                    fld(TF_OBJ, i) = (uint32_t)h.obj;
+                    meta |= (uint32_t)h.type << 4;
+                    kind = 1;
+                    if (depth < RT_MAX_BOUNCES && h.type == RT_SPHERE) {
+                        const int mat = ldc(&sc.spheres[h.obj].mat), mtype = ldc(&sc.materials[mat].type);
+                        if (mtype != RT_MAT_DIFFUSE) {
+                            bn = bounce_rays(sc, mtype, mat, h.p, h.n, d);
+                            kind = 2 + bn.kind;
+                            nchild = bn.kind == 1u ? 2u : 1u;
+                            if (mtype == RT_MAT_GLASS) { /* its Phong colour is never used: only what Scene::phong would have counted */
+                                Rng none; none.key = 0; none.k = 0;
+                                skip_shade(sc, none, cnt);
+                            }
+                        }
+                    }
+                }
+            }
+            const uint64_t m1 = __ballot(nchild >= 1u), m2 = __ballot(nchild == 2u);
+            const uint32_t n1 = (uint32_t)__popcll(m1), total = n1 + (uint32_t)__popcll(m2);
+            if (next + total > RT_TREE_NODES) return false; /* wave-uniform: the batch does not fit */
+            if (nchild >= 1u) {
+                c1 = next + wave_rank(m1, lane);
+                put3(TF_A0, c1, bn.ro);
+                put3(TF_A0 + 3, c1, bn.rd);
+                fld(TF_META, c1) = meta & 0xffffff00u;
+            }
+            if (nchild == 2u) {
+                c2 = next + n1 + wave_rank(m2, lane);
+                put3(TF_A0, c2, bn.to);
+                put3(TF_A0 + 3, c2, bn.td);
+                fld(TF_META, c2) = meta & 0xffffff00u;
+            }
+            if (active) {
+                fld(TF_META, i) = meta | kind;
+                fld(TF_F, i) = __float_as_uint(bn.F);
+                fld(TF_C1, i) = c1;
+                fld(TF_C2, i) = c2;
+            }
+            next += total;
+        }
+        ls = le; le = next;
+        if (lane == 0) s_lv[depth + 1] = ls;
+        tree_sync();
+    }
+    const uint32_t n_nodes = le, n_levels = depth; /* level l = nodes [s_lv[l], s_lv[l + 1]), s_lv[n_levels] = n_nodes */
+    wave_lds_sync();
+    /* 2. hit nodes per subtree, deepest level first */
+    for (uint32_t l = n_levels; l-- > 0;) {
+        const uint32_t b = s_lv[l], e = s_lv[l + 1];
+        for (uint32_t i = b + lane; i < e; i += 64) {
+            const uint32_t kind = fld(TF_META, i) & 15u, c1 = fld(TF_C1, i), c2 = fld(TF_C2, i);
+            fld(TF_SIZE, i) = (kind != 0u ? 1u : 0u) + (c1 ? fld(TF_SIZE, c1) : 0u) + (c2 ? fld(TF_SIZE, c2) : 0u);
+        }
+        tree_sync();
+    }
+    /* 3. position among the hit nodes of the sample in depth-first order, top level first */
+    if (lane < n_samples) fld(TF_PRE, lane) = 0;
+    tree_sync();
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        const uint32_t b = s_lv[l], e = s_lv[l + 1];
+        for (uint32_t i = b + lane; i < e; i += 64) {
+            const uint32_t c1 = fld(TF_C1, i), c2 = fld(TF_C2, i), pre = fld(TF_PRE, i);
+            if (c1) fld(TF_PRE, c1) = pre + 1u;
+            if (c2) fld(TF_PRE, c2) = pre + 1u + fld(TF_SIZE, c1);
+        }
+        tree_sync();
+    }
+    /* 4. the nodes Scene::phong's result is used of (every hit that is not a glass node with children), compacted */
+    uint32_t n_list = 0;
+    for (uint32_t c = 0; c < n_nodes; c += 64) {
+        const uint32_t i = c + lane;
+        const uint32_t kind = i < n_nodes ? (fld(TF_META, i) & 15u) : 0u;
+        const bool want = kind == 1u || kind == 2u;
+        const uint64_t m = __ballot(want);
+        if (want) fld(TF_LIST, n_list + wave_rank(m, lane)) = i;
+        n_list += (uint32_t)__popcll(m);
+    }
+    tree_sync();
+    /* 5. shade them, one lane per node */
+    for (uint32_t c = 0; c < n_list; c += 64) {
+        if (c + lane < n_list) {
+            const uint32_t i = fld(TF_LIST, c + lane);
+            const uint32_t meta = fld(TF_META, i);
+            FullHit h;
+            h.hit = true; h.type = (int)((meta >> 4) & 15u); h.obj = (int)fld(TF_OBJ, i); h.tri = -1; h.t = 0.f;
+            h.p = get3(TF_A0, i); h.n = get3(TF_A0 + 3, i);
+            Rng rng;
+            rng.key = rt_rng_key(rp.seed, x + y * rp.w, rp.sample0 + s_first + (meta >> 8));
+            rng.k = 2u + draws_per_node * fld(TF_PRE, i);
+            put3(TF_A0, i, shade<M>(sc, h, rng, cnt));
+        }
+    }
+    tree_sync();
+    /* 6. colours upwards: R/src/Scene.h:655 (mirror), :705 (glass), a miss is black (:602-605) */
+    for (uint32_t l = n_levels; l-- > 0;) {
+        const uint32_t b = s_lv[l], e = s_lv[l + 1];
+        for (uint32_t i = b + lane; i < e; i += 64) {
+            const uint32_t kind = fld(TF_META, i) & 15u;
+            if (kind == 1u) continue;
+            f3 ret = mk3(0.f, 0.f, 0.f);
+            if (kind == 2u) {
+                const f3 col = get3(TF_A0, i), r = get3(TF_A0, fld(TF_C1, i));
+                const f3 ks = ld3c(sc.materials[ldc(&sc.spheres[fld(TF_OBJ, i)].mat)].ks);
+                ret = mk3(col.x + r.x * ks.x, col.y + r.y * ks.y, col.z + r.z * ks.z);
+            } else if (kind == 3u) {
+                const float F = __uint_as_float(fld(TF_F, i));
+                ret = F * get3(TF_A0, fld(TF_C1, i)) + (1.0f - F) * get3(TF_A0, fld(TF_C2, i));
+            } else if (kind == 4u) {
+                const float F = __uint_as_float(fld(TF_F, i));
+                ret = F * get3(TF_A0, fld(TF_C1, i)) + (1.0f - F) * mk3(0.f, 0.f, 0.f);
+            }
+            put3(TF_A0, i, ret);
+        }
+        tree_sync();
+    }
+    if (lane < n_samples) {
+        const f3 col = get3(TF_A0, lane);
+        float* dst = colors + 3ull * (s_first + lane);
+        dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+    }
+    tree_sync(); /* the next batch overwrites the tree */
+    return true;
+}
+template <int M>
+RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ cam, const RenderParams& rp, const DeepList& dl, uint32_t worker,
+                            uint32_t spp, uint32_t sample0, uint32_t* s_lv, Cnt& cnt) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t* mem = dl.tree + (size_t)worker * RT_TREE_NODES * RT_TREE_WORDS;
+    RenderParams pass = rp; /* the worker handles all samples of the pass, whatever piece of it this launch renders */
+    pass.spp = spp; pass.sample0 = sample0;
+    uint32_t draws = 0;
+    for (uint32_t li = 0; li < sc.n_lights; ++li) draws += ldc(&sc.lights[li].type) == RT_LIGHT_QUAD ? 32u : 0u;
+    const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
+    const uint32_t n_deep = min(dl.head[0], dl.cap);
+    const uint32_t groups = (spp + RT_TREE_BATCH - 1) / RT_TREE_BATCH;
+    const uint64_t n_items = (uint64_t)n_deep * groups;
+    uint32_t samples = 0;
+    for (;;) { /* ends for every worker: the counter only grows and n_items is fixed */
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(&dl.head[1], 1u);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= n_items) break;
+        const uint32_t entry = item / groups, grp = item % groups;
+        const uint32_t pix = dl.pixels[entry];
+        const uint32_t local_tile = pix / px_per_tile, in_tile = pix % px_per_tile;
+        const uint32_t tile = rp.rank + local_tile * rp.world;
+        const uint32_t x = rt_tile_column(tile, rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
+        const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
+        const uint32_t s_end = min(spp, (grp + 1) * RT_TREE_BATCH);
+        uint32_t s0 = grp * RT_TREE_BATCH, batch = RT_TREE_BATCH;
+        while (s0 < s_end) {
+            const uint32_t n = min(batch, s_end - s0);
+            const Cnt before = cnt; /* a batch that does not fit is traced again in halves: its counts are dropped */
+            if (tree_batch<M>(sc, cam, pass, mem, s_lv, x, y, s0, n, draws, dl.colors + 3ull * (uint64_t)entry * spp, cnt)) {
+                s0 += n;
+                if (lane == 0) samples += n;
+            } else {
+                cnt = before;
+                batch = max(1u, n / 2);
+            }
+        }
+    }
+    return samples;
+}
+
+#ifdef RT_SHADE_HIST
+extern "C" int rt_debug_shade_hist(unsigned long long* out65, int reset) {
+    if (reset) { unsigned long long z[65] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_hist), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out65, HIP_SYMBOL(rt_dbg_hist), 65 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef RT_WAVE_TIMES /* debug build only: start / end clock of every wave of k_render */
 __device__ unsigned long long* rt_dbg_times;
 extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
@@ -168,9 +443,19 @@ extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
  *               per pixel do not leave most lanes idle. */
 template <int M, bool PACK>
 __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
-                                                uint64_t* __restrict__ counters, const uint32_t* __restrict__ order) {
+                                                uint64_t* __restrict__ counters, const uint32_t* __restrict__ order, DeepList dl, uint32_t n_workers,
+                                                uint32_t pass_spp, uint32_t pass_sample0) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (uint32_t)RT_RENDER_WAVES + (threadIdx.x >> 6);
+    __shared__ uint32_t s_stack[RT_STACK_LDS * 64 * RT_RENDER_WAVES];
+    if (blockIdx.x < n_workers) { /* the first workgroups of the launch expand the path trees of the deep list (n_workers > 0 only with RT_RENDER_WAVES == 1) */
+        __shared__ uint32_t s_lv[16];
+        Cnt wc = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES);
+        const uint32_t done = tree_worker<M>(sc, cam, rp, dl, blockIdx.x, pass_spp, pass_sample0, s_lv, wc);
+        flush_counters<M>(counters, wc, done);
+        return;
+    }
+    const uint8_t* __restrict__ deep_flags = dl.flags;
+    const uint32_t wave = (blockIdx.x - n_workers) * (uint32_t)RT_RENDER_WAVES + (threadIdx.x >> 6);
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
     const uint32_t px_per_wave = PACK ? 64u / rp.spp : 1u;
     const uint32_t waves_per_tile = PACK ? (px_per_tile + px_per_wave - 1) / px_per_wave : px_per_tile;
@@ -182,13 +467,14 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
 #endif
     const uint32_t sub = PACK ? lane / rp.spp : 0u;           /* pixel of the wave this lane works for */
     const uint32_t in_tile = (wave - slot * waves_per_tile) * px_per_wave + sub;
-    const bool has_pixel = wave_has_tile && sub < px_per_wave && in_tile < px_per_tile;
+    bool has_pixel = wave_has_tile && sub < px_per_wave && in_tile < px_per_tile;
+    /* a pixel on the deep list is left to k_render_wide / k_resolve_deep */
+    if (deep_flags && has_pixel && deep_flags[(uint64_t)local_tile * px_per_tile + in_tile]) has_pixel = false;
     const uint32_t tile = rp.rank + local_tile * rp.world;
     const uint32_t x = rt_tile_column(tile, rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
     const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
     float* dst = out + 3ull * ((uint64_t)local_tile * px_per_tile + in_tile);
     const bool in_image = has_pixel && x < rp.w && y < rp.h; /* padding pixels of edge tiles stay 0 */
-    __shared__ uint32_t s_stack[RT_STACK_LDS * 64 * RT_RENDER_WAVES];
     /* path frames: the first L levels in LDS.  A variant without a BVH never touches s_stack (the compiler drops it), so at
      * 4 waves / SIMD = 16 waves per CU each wave can have 10 KB of the CU's 160 KB; the variants that traverse a BVH
      * need their LDS for the traversal stack and keep the frames in the per-lane array */
@@ -249,6 +535,20 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
 #endif
     flush_counters<M>(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
 }
+/* image[x + y*w] += colour, sample after sample (R/main.cpp:191), for the pixels of the deep list; the pass that
+ * reaches spp_total divides (R/main.cpp:193) -- what k_render does for the other pixels.  One thread per pixel. */
+__global__ __launch_bounds__(256) void k_resolve_deep(RenderParams rp, DeepList dl, float* __restrict__ out) {
+    const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
+    if (entry >= min(dl.head[0], dl.cap)) return;
+    float* dst = out + 3ull * dl.pixels[entry];
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (rp.sample0 > 0) acc = ld3(dst);
+    const float* c = dl.colors + 3ull * (uint64_t)entry * rp.spp;
+    for (uint32_t s = 0; s < rp.spp; ++s) { acc.x += c[3 * s]; acc.y += c[3 * s + 1]; acc.z += c[3 * s + 2]; }
+    if (rp.sample0 + rp.spp == rp.spp_total) acc = acc / (float)rp.spp_total;
+    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+}
+
 /* one thread per pixel: find the pixel in the rank-major tile buffers, quantise like R/main.cpp:213 */
 __global__ __launch_bounds__(256) void k_tiles_to_rgb8(const float* __restrict__ tiles, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h,
                                                        uint32_t tiles_x, uint32_t world, uint32_t per_rank, uint8_t* __restrict__ out) {
@@ -445,8 +745,14 @@ struct Lib {
     int cam_last_slot = -1;     /* same stream with the same camera does not upload it again                           */
     void* cam_last_stream = nullptr;
     /* workspaces of k_tile_class / k_tile_place, one per render call in turn, grown on demand */
-    uint32_t* order_ws[kOrderSlots] = {};
-    size_t order_cap[kOrderSlots] = {};
+    uint32_t* order_ws[kOrderSlots] = {};   /* keys, order, then the deep list: head, pixels, flags, colours */
+    size_t order_cap[kOrderSlots] = {};     /* bytes */
+    size_t order_off[kOrderSlots][5] = {};  /* byte offsets of head / pixels / flags / colours / worker trees */
+    uint32_t order_workers[kOrderSlots] = {};
+    uint32_t order_deep_cap[kOrderSlots] = {};
+    size_t order_colors_bytes[kOrderSlots] = {};
+    bool wide = true;           /* RTAMD_WIDE=0 renders every pixel with one lane per path */
+    uint32_t wide_nodes = RT_PROBE_CAP; /* RTAMD_WIDE_NODES: path nodes of the centre ray from which a pixel counts as deep */
     unsigned order_next = 0;
     /* A ring slot is handed out again after kCamSlots / kOrderSlots further calls.  The launches that read it may
      * still be queued on another stream by then, so each slot carries an event recorded behind its last reader and
@@ -654,8 +960,26 @@ int rt_init(int device) {
     g.cam_last_slot = -1;
     const char* ord = std::getenv("RTAMD_TILE_ORDER");
     g.order_tiles = !(ord && ord[0] == '0');
+    const char* wd = std::getenv("RTAMD_WIDE");
+    g.wide = !(wd && wd[0] == '0');
+    const char* wn = std::getenv("RTAMD_WIDE_NODES");
+    g.wide_nodes = RT_PROBE_CAP;
+    if (wn && std::atoi(wn) >= 1 && std::atoi(wn) <= RT_PROBE_CAP) g.wide_nodes = (uint32_t)std::atoi(wn);
     g.device = device;
     g.ready = true;
+    return RT_OK;
+}
+
+int rt_set_option(const char* name, int64_t value) {
+    if (!name) return fail(RT_E_INVALID, "rt_set_option: null name");
+    const std::string k(name);
+    if (k == "tile_order") g.order_tiles = value != 0;
+    else if (k == "wide") g.wide = value != 0;
+    else if (k == "wide_nodes") {
+        if (value < 1 || value > RT_PROBE_CAP) return fail(RT_E_INVALID, "rt_set_option: wide_nodes must lie in 1 .. 24");
+        g.wide_nodes = (uint32_t)value;
+    } else return fail(RT_E_INVALID, "rt_set_option: unknown option " + k);
+    g.order_last_slot = -1; /* a cached launch order / deep list was made under the old settings */
     return RT_OK;
 }
 
@@ -1039,56 +1363,98 @@ static int render_pass(bool static_mem, rt_scene_t scene, const rt_camera* cam, 
         g.cam_last = *cam; g.cam_last_slot = cam_slot; g.cam_last_stream = hip_stream;
     }
     const uint32_t* d_order = nullptr;
-    /* Without bounces every tree has one node: nothing to order.  With a triangle BVH in the scene the probe has to
-     * traverse it for every pixel (3.9 ms of a 29 ms frame on 10 M triangles) and the order it finds gains nothing:
-     * there the long waves are the ones whose shadow rays skim the mesh, which the probe does not see. */
-    if (g.order_tiles && r->has_bounce && !(r->mode & RT_M_BVH) && rp.n_local_tiles > 1) {
+    DeepList dl;
+    std::memset(&dl, 0, sizeof(dl));
+    /* The probe (k_tile_class) serves two things.  Launch order: without bounces every tree has one node, nothing to order;
+     * with a triangle BVH the order gains nothing (there the long waves are the ones whose shadow rays skim the mesh, which
+     * the probe does not see).  Deep list: the pixels whose centre ray has a tree of wide_nodes nodes or more go to
+     * k_render_wide; that needs memory for their samples' colours, so not in the allocation-free call. */
+    const bool want_order = g.order_tiles && r->has_bounce && !(r->mode & RT_M_BVH) && rp.n_local_tiles > 1;
+    const bool want_wide = g.wide && r->has_bounce && !static_mem;
+    if (want_order || want_wide) {
         uint32_t* ws = nullptr;
+        bool fresh = true;
         if (static_mem) ws = (uint32_t*)(g.scratch_ptr + RT_NOALLOC_CAM_BYTES);
         else {
+            const uint64_t npx = (uint64_t)rp.n_local_tiles * tile_w * tile_h;
             Lib::OrderKey key;
             std::memset(&key, 0, sizeof(key));
             key.scene = scene; key.stream = hip_stream; key.cam = *cam; key.w = w; key.h = h; key.tile_w = tile_w; key.tile_h = tile_h; key.rank = rank; key.world = world;
-            if (sample0 > 0 && g.order_last_slot >= 0 && std::memcmp(&key, &g.order_key, sizeof(key)) == 0) {
-                order_slot = g.order_last_slot; /* same stream as the probe that filled it */
-                d_order = g.order_ws[order_slot] + rp.n_local_tiles;
+            if (sample0 > 0 && g.order_last_slot >= 0 && std::memcmp(&key, &g.order_key, sizeof(key)) == 0 &&
+                (!want_wide || (uint64_t)g.order_deep_cap[g.order_last_slot] * spp * 12 <= g.order_colors_bytes[g.order_last_slot])) {
+                order_slot = g.order_last_slot; /* same stream as the probe that filled it: the later passes of a progressive render */
+                fresh = false;
             } else {
                 const unsigned slot = g.order_next++ % kOrderSlots;
-                const size_t words = 2 * (size_t)rp.n_local_tiles;
+                /* at most a quarter of the pixels (beyond that the launch is full of long waves anyway) and 512 MiB of colours */
+                uint64_t cap = want_wide ? std::max<uint64_t>(64, npx / 4) : 0;
+                if (want_wide) cap = std::max<uint64_t>(1, std::min<uint64_t>(cap, (512ull << 20) / ((uint64_t)spp * 12)));
+                const size_t off_head = (2 * (size_t)rp.n_local_tiles * 4 + 15) & ~(size_t)15;
+                const size_t off_pixels = off_head + 16, off_flags = off_pixels + (size_t)cap * 4;
+                const size_t off_colors = (off_flags + (want_wide ? (size_t)npx : 0) + 15) & ~(size_t)15;
+                const size_t colors_bytes = (size_t)cap * spp * 12;
+                /* worker waves: at most half of what the chip holds at 4 waves per SIMD, and no more than there can be items */
+                const uint32_t workers = (uint32_t)std::min<uint64_t>(2048, cap * ((spp + RT_TREE_BATCH - 1) / RT_TREE_BATCH));
+                const size_t off_tree = (off_colors + colors_bytes + 255) & ~(size_t)255;
+                const size_t bytes = off_tree + (size_t)workers * RT_TREE_NODES * RT_TREE_WORDS * 4;
                 if (g.order_used[slot] && g.order_stream[slot] != hip_stream) HIP_TRY(hipStreamWaitEvent(st, g.order_done[slot], 0));
-                if (g.order_cap[slot] < words) {
+                if (g.order_cap[slot] < bytes) {
                     /* hipFree waits for the device, so no launch still reads the old block */
                     if (g.order_ws[slot]) { HIP_TRY(hipFree(g.order_ws[slot])); g.order_ws[slot] = nullptr; g.order_cap[slot] = 0; }
-                    HIP_TRY(hipMalloc((void**)&g.order_ws[slot], words * 4));
-                    g.order_cap[slot] = words;
+                    HIP_TRY(hipMalloc((void**)&g.order_ws[slot], bytes));
+                    g.order_cap[slot] = bytes;
                 }
-                ws = g.order_ws[slot];
+                g.order_off[slot][0] = off_head; g.order_off[slot][1] = off_pixels; g.order_off[slot][2] = off_flags; g.order_off[slot][3] = off_colors; g.order_off[slot][4] = off_tree;
+                g.order_workers[slot] = workers;
+                g.order_deep_cap[slot] = (uint32_t)cap; g.order_colors_bytes[slot] = colors_bytes;
                 g.order_key = key;
                 g.order_last_slot = order_slot = (int)slot;
             }
+            unsigned char* mem = (unsigned char*)g.order_ws[order_slot];
+            ws = (uint32_t*)mem;
+            if (want_wide && g.order_deep_cap[order_slot] > 0) {
+                dl.head = (uint32_t*)(mem + g.order_off[order_slot][0]);
+                dl.pixels = (uint32_t*)(mem + g.order_off[order_slot][1]);
+                dl.flags = mem + g.order_off[order_slot][2];
+                dl.colors = (float*)(mem + g.order_off[order_slot][3]);
+                dl.tree = (uint32_t*)(mem + g.order_off[order_slot][4]);
+                dl.n_workers = g.order_workers[order_slot];
+                dl.cap = g.order_deep_cap[order_slot];
+                dl.min_nodes = g.wide_nodes;
+                /* a new list starts empty; a list used again only restarts k_render_wide's queue */
+                if (fresh) HIP_TRY(hipMemsetAsync(dl.head, 0, 16, st));
+                else HIP_TRY(hipMemsetAsync(dl.head + 1, 0, 4, st));
+            }
         }
-        if (ws) {
-            RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws);
-            hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
+        if (fresh) {
+            RT_DISPATCH(r->mode, k_tile_class, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws, dl);
+            if (want_order) hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
             HIP_TRY(hipGetLastError());
-            d_order = ws + rp.n_local_tiles;
         }
+        if (want_order) d_order = ws + rp.n_local_tiles;
     }
     /* The samples of the call are cut so that every launch fills its waves: whole 64-sample chunks go to the
      * wave-per-pixel kernel, what is left to the packed kernel in pieces of at most 32 (2 pixels per wave,
      * then 64 / rest pixels per wave).  50 spp = 32 + 18 keeps 94 % of the lanes busy where one wave per
      * pixel keeps 78 %.  The launches continue each other's sums through the tile buffer like passes do. */
     uint32_t left = spp, s0 = sample0;
+    uint32_t n_workers = dl.flags ? dl.n_workers : 0u; /* in the first launch of the pass only: they take all its samples */
     while (left > 0) {
         const uint32_t n = left >= 64 ? (left / 64) * 64 : (left > 32 ? 32 : left);
         const bool pack = n <= 32;
         const uint32_t px_per_wave = pack ? 64u / n : 1u;
         const uint64_t waves = (uint64_t)rp.n_local_tiles * (((uint64_t)tile_w * tile_h + px_per_wave - 1) / px_per_wave);
         rp.spp = n; rp.sample0 = s0;
-        dim3 grid((unsigned)((waves + RT_RENDER_WAVES - 1) / RT_RENDER_WAVES));
-        RT_DISPATCH_RENDER(r->mode, pack, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order);
+        dim3 grid((unsigned)((waves + RT_RENDER_WAVES - 1) / RT_RENDER_WAVES) + n_workers);
+        RT_DISPATCH_RENDER(r->mode, pack, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order, dl, n_workers, spp, sample0);
         HIP_TRY(hipGetLastError());
         s0 += n; left -= n;
+        n_workers = 0;
+    }
+    if (dl.flags) { /* the sums of the listed pixels, from the colours the workers left */
+        rp.spp = spp; rp.sample0 = sample0;
+        hipLaunchKernelGGL(k_resolve_deep, dim3(blocks_for(dl.cap)), dim3(256), 0, st, rp, dl, d_rgb_tiles);
+        HIP_TRY(hipGetLastError());
     }
     /* the ring slots this call read are busy until here */
     if (cam_slot >= 0) { HIP_TRY(hipEventRecord(g.cam_done[cam_slot], st)); g.cam_used[cam_slot] = true; g.cam_stream[cam_slot] = hip_stream; }

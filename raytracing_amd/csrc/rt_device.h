@@ -574,7 +574,7 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
     return kd_closest<M>(sc, o, d, t_in, t_out, cnt, best) && best.type >= 0 && best.t < dist;
 }
 
-/* Shadow queries of one shaded point, RT_SB at a time (root-leaf scenes).  All rays of a batch leave the
+/* Shadow queries of one shaded point, SB at a time (root-leaf scenes).  All rays of a batch leave the
  * same origin, so everything that depends on (origin, object) only -- the sphere's o - c and
  * |o - c|^2 - r^2, the square's dot(v0 - o, n), a triangle's o - v0 and cross(o - v0, e1) -- is
  * computed once per object and reused by every direction of the batch, each object record is fetched
@@ -584,16 +584,16 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
 #ifndef RT_SB
 #define RT_SB 4
 #endif
-template <int M>
-RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[RT_SB], const float dist[RT_SB], bool occ[RT_SB], uint32_t& near,
+template <int M, int SB>
+RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&d)[SB], const float (&dist)[SB], bool (&occ)[SB], uint32_t& near,
                          Cnt& cnt) {
-    bool act[RT_SB];
-    cnt.rays += RT_SB;
+    bool act[SB];
+    cnt.rays += SB;
 #pragma unroll
-    for (int j = 0; j < RT_SB; ++j) { act[j] = true; occ[j] = false; }
+    for (int j = 0; j < SB; ++j) { act[j] = true; occ[j] = false; }
     if (__builtin_expect(!o_inside, 0)) { /* the origin left the root box: the slab test decides, ray by ray */
 #pragma unroll
-        for (int j = 0; j < RT_SB; ++j) {
+        for (int j = 0; j < SB; ++j) {
             float t_in, t_out;
             act[j] = box_test(sc.box_lo, sc.box_hi, o, d[j], t_in, t_out);
         }
@@ -605,10 +605,10 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
         f3 oc = o - ld3(s.c);
         float n = len3(oc);
         float c = (n * n) - s.r2;
-        float b[RT_SB], delta[RT_SB];
+        float b[SB], delta[SB];
         bool some = false;
 #pragma unroll
-        for (int j = 0; j < RT_SB; ++j) {
+        for (int j = 0; j < SB; ++j) {
             float a = dot3(d[j], d[j]);
             b[j] = dot3(2.f * d[j], oc);
             delta[j] = b[j] * b[j] - 4.f * a * c;
@@ -616,7 +616,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
         }
         if (!some) return; /* every line of the batch misses the sphere */
 #pragma unroll
-        for (int j = 0; j < RT_SB; ++j) {
+        for (int j = 0; j < SB; ++j) {
             float a = dot3(d[j], d[j]);
             float t = RT_INF; /* stays +inf (never < dist) when the sphere is missed */
             if (delta[j] > 0.f) {
@@ -638,22 +638,22 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
      * value below -1e-30 means the correctly rounded t is negative, and a value above dist * (1 + 2^-20)
      * means it is >= dist: both are misses whatever the rectangle test would say.  Everything else
      * (including NaN, zero and denormal results) takes the reference's division. */
-    float dist_hi[RT_SB];
+    float dist_hi[SB];
 #pragma unroll
-    for (int j = 0; j < RT_SB; ++j) dist_hi[j] = dist[j] * 1.000001f;
+    for (int j = 0; j < SB; ++j) dist_hi[j] = dist[j] * 1.000001f;
     for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t) {
         f3 v0 = ld3(q.v0), n = ld3(q.n);
         float num = dot3(v0 - o, n);
-        bool maybe[RT_SB], some = false;
+        bool maybe[SB], some = false;
 #pragma unroll
-        for (int j = 0; j < RT_SB; ++j) {
+        for (int j = 0; j < SB; ++j) {
             float ta = num * __builtin_amdgcn_rcpf(dot3(d[j], n));
             maybe[j] = !(ta < -1e-30f) && !(ta > dist_hi[j]);
             some = some || maybe[j];
         }
         if (!some) return;
 #pragma unroll
-        for (int j = 0; j < RT_SB; ++j)
+        for (int j = 0; j < SB; ++j)
             if (maybe[j]) {
                 float tt = num / dot3(d[j], n);
                 if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
@@ -668,7 +668,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
             f3 qv = cross3(sv, e1);
             float e2q = dot3(e2, qv);
 #pragma unroll
-            for (int j = 0; j < RT_SB; ++j) {
+            for (int j = 0; j < SB; ++j) {
                 f3 h = cross3(d[j], e2);
                 float a = dot3(e1, h);
                 float f = 1.0f / a;
@@ -681,7 +681,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
         });
     }
 #pragma unroll
-    for (int j = 0; j < RT_SB; ++j) occ[j] = occ[j] && act[j];
+    for (int j = 0; j < SB; ++j) occ[j] = occ[j] && act[j];
     /* Large meshes are not walked here: few rays come near one, and a wave would pay a whole traversal per batch
      * for a handful of them.  The rays still undecided that reach the bounds of some mesh with a BVH are reported
      * in `near` and walked later, all light samples of the shaded point together (walk_deferred). */
@@ -691,7 +691,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 d[
             const DMesh m = ldc(&sc.meshes[mi]);
             if (m.bvh_root < 0) continue;
 #pragma unroll
-            for (int j = 0; j < RT_SB; ++j)
+            for (int j = 0; j < SB; ++j)
                 if (!occ[j] && act[j] && bvh_reaches<true>(m, o, d[j], dist[j])) near |= 1u << j;
         }
 }
@@ -829,10 +829,19 @@ RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
     return type == RT_SPHERE ? ldc(&sc.spheres[obj].mat) : (type == RT_SQUARE ? ldc(&sc.squares[obj].mat) : ldc(&sc.meshes[obj].mat));
 }
 
+#ifdef RT_SHADE_HIST /* debug build only: how many lanes of a wave shade a node together */
+__device__ unsigned long long rt_dbg_hist[65];
+#endif
 /* ---- Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276) ------------------ */
 template <int M>
 RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     ++cnt.nodes;
+#ifdef RT_SHADE_HIST
+    { /* the predicate depends on per-lane data so that the ballot cannot be moved out of the (divergent) path loop */
+        const uint64_t act = __ballot(cnt.nodes != 0u);
+        if (wave_rank(act, __lane_id()) == 0u) atomicAdd(&rt_dbg_hist[__popcll(act)], 1ull);
+    }
+#endif
     const DMaterial m = ldc(&sc.materials[material_index(sc, h.type, h.obj)]);
     f3 ambient = 0.35f * mk3(0.2f, 0.2f, 0.2f);
     f3 diffuse = mk3(0.f, 0.f, 0.f), specular = mk3(0.f, 0.f, 0.f);
@@ -864,7 +873,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
-                    shadow_batch<M>(sc, so, so_inside, Ld, dist, occ, near4, cnt);
+                    shadow_batch<M, RT_SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt);
                     if (!(M & RT_M_BVH)) { /* every ray is decided: add the light terms in sample order right away */
 #pragma unroll
                         for (int j = 0; j < RT_SB; ++j)
@@ -924,6 +933,45 @@ RT_DEV void skip_shade(const DeviceScene& sc, Rng& rng, Cnt& cnt) {
     }
 }
 
+/* The rays a hit on a mirror or glass sphere sends on, R/src/Scene.h:641-702.  kind 0: mirror, (ro, rd) the reflected ray;
+ * kind 1: glass, reflected ray (ro, rd) and refracted ray (to, td), F the Fresnel weight of the reflected colour;
+ * kind 2: glass without a refracted ray (total internal reflection, or F rounds to 1).  mtype is RT_MAT_MIRROR or RT_MAT_GLASS. */
+struct Bounce { f3 ro, rd, to, td; float F; uint32_t kind; };
+RT_DEV Bounce bounce_rays(const DeviceScene& sc, int mtype, int mat, f3 P, f3 N, f3 I) {
+    Bounce b;
+    b.to = b.td = mk3(0.f, 0.f, 0.f);
+    b.F = 0.f;
+    if (mtype == RT_MAT_MIRROR) {
+        f3 R = I - (2.0f * dot3(I, N)) * N;
+        b.ro = P + 0.001f * N; b.rd = norm3_unit(R);
+        b.kind = 0u;
+        return b;
+    }
+    float n1 = 1.0f, n2 = ldc(&sc.materials[mat].ior);
+    if (dot3(I, N) > 0.0f) { float s = n1; n1 = n2; n2 = s; N = -1.0f * N; }
+    float cosI = __builtin_fabsf(dot3(I, N));
+    float eta = n1 / n2;
+    float sinT2 = eta * eta * (1.0f - cosI * cosI);
+    float F;
+    if (sinT2 > 1.0f) F = 1.0f;
+    else {
+        float cosT = __builtin_sqrtf(1.0f - sinT2);
+        float rs = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+        float rp = (n1 * cosT - n2 * cosI) / (n1 * cosT + n2 * cosI);
+        /* pow(x, 2) in double = exact square rounded once = the float product */
+        F = (rs * rs + rp * rp) / 2.0f;
+    }
+    f3 R = I - (2.0f * dot3(I, N)) * N;
+    b.F = F;
+    if (F < 1.0f) {
+        f3 T = eta * (I - cosI * N) - __builtin_sqrtf(1.0f - sinT2) * N;
+        b.to = P - 0.001f * N; b.td = norm3_unit(T);
+        b.kind = 1u;
+    } else b.kind = 2u;
+    b.ro = P + 0.001f * N; b.rd = norm3_unit(R);
+    return b;
+}
+
 /* ---- Scene::rayTraceRecursive, R/src/Scene.h:596-713, as a loop --------------------------
  * The recursion (depth <= 11, reflected child before refracted child) becomes a loop over
  * "calls" with a small per-lane frame stack; the colour arithmetic on the way back up is the
@@ -976,6 +1024,9 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
     uint32_t kinds = 0; /* bits 2 l, 2 l + 1: kind of the frame at level l */
     f3 ret = mk3(0.f, 0.f, 0.f);
     for (;;) {
+#ifdef RT_SHADE_HIST
+        if (!PROBE) { const uint64_t act = __ballot(sp >= 0); if (wave_rank(act, __lane_id()) == 0u) atomicAdd(&rt_dbg_hist[0], 1ull); }
+#endif
         HitRec rec = closest_rec<M>(sc, o, d, cnt);
         bool descended = false;
         if (rec.type < 0) ret = mk3(0.f, 0.f, 0.f);
@@ -990,49 +1041,22 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
             else col = shade<M>(sc, h, rng, cnt);
             ret = col;
             if (bounces && mtype != RT_MAT_DIFFUSE) {
-                f3 P = h.p, N = h.n, I = d;
+                const Bounce bn = bounce_rays(sc, mtype, mat, h.p, h.n, d);
                 float f[RT_FRAME_WORDS];
-                if (mtype == RT_MAT_MIRROR) {
-                    f3 R = I - (2.0f * dot3(I, N)) * N;
+                if (bn.kind == 0u) {
                     f[0] = col.x; f[1] = col.y; f[2] = col.z; f[3] = __int_as_float(mat);
                     stk.template put<0, 4>(sp, f);
-                    kinds &= ~(3u << (2 * sp));
-                    ++sp;
-                    o = P + 0.001f * N; d = norm3_unit(R);
-                    descended = true;
-                } else if (mtype == RT_MAT_GLASS) {
-                    float n1 = 1.0f, n2 = ldc(&sc.materials[mat].ior);
-                    if (dot3(I, N) > 0.0f) { float s = n1; n1 = n2; n2 = s; N = -1.0f * N; }
-                    float cosI = __builtin_fabsf(dot3(I, N));
-                    float eta = n1 / n2;
-                    float sinT2 = eta * eta * (1.0f - cosI * cosI);
-                    float F;
-                    if (sinT2 > 1.0f) F = 1.0f;
-                    else {
-                        float cosT = __builtin_sqrtf(1.0f - sinT2);
-                        float rs = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
-                        float rp = (n1 * cosT - n2 * cosI) / (n1 * cosT + n2 * cosI);
-                        /* pow(x, 2) in double = exact square rounded once = the float product */
-                        F = (rs * rs + rp * rp) / 2.0f;
-                    }
-                    f3 R = I - (2.0f * dot3(I, N)) * N;
-                    f[6] = F;
-                    uint32_t kind;
-                    if (F < 1.0f) {
-                        f3 T = eta * (I - cosI * N) - __builtin_sqrtf(1.0f - sinT2) * N;
-                        f3 to = P - 0.001f * N, td = norm3_unit(T);
-                        f[0] = to.x; f[1] = to.y; f[2] = to.z; f[3] = td.x; f[4] = td.y; f[5] = td.z;
-                        stk.template put<0, 7>(sp, f);
-                        kind = 1u;
-                    } else {
-                        stk.template put<6, 1>(sp, f);
-                        kind = 2u;
-                    }
-                    kinds = (kinds & ~(3u << (2 * sp))) | (kind << (2 * sp));
-                    ++sp;
-                    o = P + 0.001f * N; d = norm3_unit(R);
-                    descended = true;
+                } else if (bn.kind == 1u) {
+                    f[0] = bn.to.x; f[1] = bn.to.y; f[2] = bn.to.z; f[3] = bn.td.x; f[4] = bn.td.y; f[5] = bn.td.z; f[6] = bn.F;
+                    stk.template put<0, 7>(sp, f);
+                } else {
+                    f[6] = bn.F;
+                    stk.template put<6, 1>(sp, f);
                 }
+                kinds = (kinds & ~(3u << (2 * sp))) | (bn.kind << (2 * sp));
+                ++sp;
+                o = bn.ro; d = bn.rd;
+                descended = true;
             }
         }
         if (descended) continue;

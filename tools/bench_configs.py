@@ -10,16 +10,13 @@ usage: bench_configs.py --config c4|c5 [--world 8] [--ranks 0,3,7] [--spp N] [--
 import argparse
 import os
 import sys
-import tempfile
 import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from raytracing_amd import api, host, parallel_render  # noqa: E402
-from tests import scenegen  # noqa: E402
-from tools import make_mesh_off  # noqa: E402
+from raytracing_amd import api, host, parallel_render, workloads  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", required=True, choices=["c4", "c5"])
@@ -33,44 +30,11 @@ a = ap.parse_args()
 api.init(0)
 dev = torch.device("cuda", 0)
 t0 = time.perf_counter()
-if a.config == "c4":
-    w, h, spp = 3840, 2160, a.spp or 256
-    off = os.path.join(tempfile.gettempdir(), "grid_709.off")
-    if not os.path.exists(off):
-        make_mesh_off.write_off(off, *make_mesh_off.make(709))
-    hs = host.HostScene.mesh_file(off, with_spheres=True)
-    t1 = time.perf_counter()
-    scene = hs.upload()
-    pass_spp = spp
-else:
-    w, h, spp = 1920, 1080, a.spp or 64
-    n = 2237
-    rng = np.random.default_rng(1)
-    xs = np.linspace(-1.9, 1.9, n, dtype=np.float32)
-    gx, gz = np.meshgrid(xs, xs, indexing="xy")
-    gy = (0.5 * np.exp(-1.5 * (gx * gx + gz * gz)) + 0.02 * rng.random((n, n), dtype=np.float32) - 1.9).astype(np.float32)
-    pos = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(np.float32)
-    idx = np.arange(n * n, dtype=np.uint32).reshape(n, n)
-    p, q, r, s = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
-    tri = np.concatenate([np.stack([p, r, q], 1), np.stack([p, s, r], 1)]).astype(np.uint32)
-    nrm = np.zeros_like(pos)
-    nrm[:, 1] = 1.0
-    box = host.HostScene.builtin(2)                      # Cornell walls, mirror + glass sphere, quad light
-    d = api.copy_struct(api.SceneDesc, box.desc)
-    mesh = (api.Mesh * 1)()
-    mesh[0].first_vertex, mesh[0].n_vertices, mesh[0].first_triangle, mesh[0].n_triangles = 0, len(pos), 0, len(tri)
-    mesh[0].material = 0
-    mesh[0].aabb_min[:] = pos.min(0)
-    mesh[0].aabb_max[:] = pos.max(0)
-    d.n_meshes, d.meshes = 1, mesh
-    d.n_vertices, d.n_triangles = len(pos), len(tri)
-    import ctypes as C
-    d.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
-    d.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
-    d.triangles = tri.ctypes.data_as(C.POINTER(C.c_uint32))
-    t1 = time.perf_counter()
-    scene = api.DeviceScene(d, keep=[box, mesh, pos, nrm, tri])
-    pass_spp = a.pass_spp
+wl = workloads.make(a.config)
+w, h, spp = wl.w, wl.h, a.spp or wl.spp
+t1 = time.perf_counter()
+scene = wl.upload()
+pass_spp = spp if a.config == "c4" else a.pass_spp
 t2 = time.perf_counter()
 info, tm = scene.verify()
 print(f"{a.config}: {info.bvh_nodes} BVH nodes (depth {info.bvh_max_depth}), {info.device_bytes / 1e6:.0f} MB of tables; host scene "

@@ -13,3 +13,10 @@ timeout -s KILL $T rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS
 timeout -s KILL $T rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$out" -o s2 -- python3 tools/prof_config.py --steps 1 "$@" > "$out/s2.log" 2>&1
 timeout -s KILL $T rocprofv3 --kernel-trace --stats -d "$out" -o kt -- python3 tools/prof_config.py --steps 3 "$@" > "$out/kt.log" 2>&1
 grep -h "step" "$out"/t1.log "$out"/kt.log
+# summaries (the result databases are tens of MB each: summarised, then dropped)
+cfg=$(echo "$@" | sed -n 's/.*--config \([a-z0-9]*\).*/\1/p')
+python3 tools/prof_summary.py "$out/kt_results.db" --kernel k_render --cmd "rocprofv3 --kernel-trace --stats -- python3 tools/prof_config.py --steps 3 $*" > "$out/kernel_trace.txt"
+python3 tools/pmc_summary.py "$out" > "$out/pmc.txt"
+python3 tools/traffic_json.py "$out" "$cfg" --out "$out/traffic_$cfg.json" > /dev/null
+grep -h "step 0" "$out"/t1.log >> "$out/pmc.txt"
+rm -f "$out"/*_results.db
