@@ -191,9 +191,11 @@ const char* rt_last_error(void);
 /* Scheduling switches of the render calls; none of them changes a result (GPU tests compare the floats).  No
  * reference counterpart.  Each also has an environment variable read by rt_init.
  *   "tile_order" 0 / 1 (RTAMD_TILE_ORDER): launch the tiles deepest-path-first (default 1) or in index order
- *   "wide"       0 / 1 (RTAMD_WIDE): render the pixels with deep path trees with several lanes per path (default 1)
- *   "wide_nodes" 1 .. 24 (RTAMD_WIDE_NODES): a pixel counts as deep when the path tree of its centre ray has at least
- *                this many nodes (default 24) */
+ *   "wide"       0 / 1 / 2 (RTAMD_WIDE): pixels with deep path trees are expanded breadth first by worker waves: never,
+ *                where it pays (default: scenes with a kd-tree of internal nodes, and launches of a scene with a triangle
+ *                BVH too small to hide a long wave), wherever something bounces
+ *   "wide_nodes" 1 .. 24 (RTAMD_WIDE_NODES): a pixel counts as deep when the path tree of its centre ray, or of one of
+ *                its corners, has at least this many nodes (default 12) */
 int rt_set_option(const char* name, int64_t value);
 
 /* Device self-test of the library's shortened divide / sqrt sequences: normalises `n` pseudo-random

@@ -123,53 +123,73 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
 #define RT_ORDER_KEYS (RT_PROBE_CAP + 1)
 template <int M>
 __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws, DeepList dl) {
+    /* The probe only has to say where path trees are deep, which the spheres decide.  In a scene whose root is a leaf
+     * it therefore leaves the meshes out: no BVH is traversed, and a 10 M-triangle scene is probed as fast as the bare box. */
+    constexpr int P = (M == RT_M_BVH) ? 0 : M;
+    if (M == RT_M_BVH) sc.n_meshes = 0;
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
-    __shared__ uint32_t s_deepest;
+    __shared__ uint32_t s_deepest, s_bounces;
     const uint32_t local_tile = blockIdx.x; /* one workgroup per tile, one thread per pixel (a 16 x 16 tile) */
     const uint32_t tile = rp.rank + local_tile * rp.world;
     const uint32_t x0 = rt_tile_column(tile, rp.tiles_x) * rp.tile_w, y0 = (tile / rp.tiles_x) * rp.tile_h;
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
-    if (threadIdx.x == 0) s_deepest = 0;
+    if (threadIdx.x == 0) { s_deepest = 0; s_bounces = 0; }
     __syncthreads();
+    auto probe = [&](uint32_t x, uint32_t y, float fx, float fy) -> uint32_t {
+        float u = ((float)(int)x + fx) / (float)(int)rp.w;
+        float v = ((float)(int)y + fy) / (float)(int)rp.h;
+        f3 o, d;
+        primary_ray(*cam, u, v, o, d);
+        Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
+        Rng rng; rng.key = 0; rng.k = 0;
+        (void)trace_path<P, true>(sc, o, norm3(d), rng, cnt);
+        return cnt.nodes;
+    };
     uint32_t deepest = 0;
+    for (uint32_t i = threadIdx.x; i < px_per_tile; i += 256) { /* the centre of every pixel */
+        const uint32_t x = x0 + i % rp.tile_w, y = y0 + i / rp.tile_w;
+        uint32_t nodes = 0;
+        if (x < rp.w && y < rp.h) nodes = probe(x, y, 0.5f, 0.5f);
+        deepest = max(deepest, nodes);
+        if (dl.flags) dl.flags[(uint64_t)local_tile * px_per_tile + i] = (uint8_t)nodes; /* for the second round */
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, off, 64));
+    if ((threadIdx.x & 63) == 0) { atomicMax(&s_deepest, deepest); if (deepest >= 2u) s_bounces = 1u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t key = (RT_ORDER_KEYS - 1) - min(s_deepest, (uint32_t)(RT_ORDER_KEYS - 1)); /* key 0 = deepest */
+        ws[local_tile] = key;
+    }
+    if (!dl.flags) return;
+    /* Deep list.  A tile some of whose pixels look at a mirror or glass sphere also probes the corners of its pixels: the
+     * samples of a pixel on the rim of a sphere differ, and one deep sample makes the pixel's wave a long one. */
+    const bool corners = s_bounces != 0u; /* the same for the whole workgroup */
     for (uint32_t i0 = 0; i0 < px_per_tile; i0 += 256) { /* every thread of the workgroup makes every trip */
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t x = x0 + i % rp.tile_w, y = y0 + i / rp.tile_w;
         const bool valid = i < px_per_tile && x < rp.w && y < rp.h;
         uint32_t nodes = 0;
         if (valid) {
-            float u = ((float)(int)x + 0.5f) / (float)(int)rp.w;
-            float v = ((float)(int)y + 0.5f) / (float)(int)rp.h;
-            f3 o, d;
-            primary_ray(*cam, u, v, o, d);
-            Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
-            Rng rng; rng.key = 0; rng.k = 0;
-            (void)trace_path<M, true>(sc, o, norm3(d), rng, cnt);
-            nodes = cnt.nodes;
-            deepest = max(deepest, nodes);
+            nodes = dl.flags[(uint64_t)local_tile * px_per_tile + i];
+            if (corners && nodes < dl.min_nodes) nodes = max(nodes, probe(x, y, 0.05f, 0.05f));
+            if (corners && nodes < dl.min_nodes) nodes = max(nodes, probe(x, y, 0.95f, 0.05f));
+            if (corners && nodes < dl.min_nodes) nodes = max(nodes, probe(x, y, 0.05f, 0.95f));
+            if (corners && nodes < dl.min_nodes) nodes = max(nodes, probe(x, y, 0.95f, 0.95f));
         }
-        if (dl.flags) { /* one atomic per wave reserves the list entries of its deep pixels */
-            const bool deep = valid && nodes >= dl.min_nodes;
-            const uint64_t mask = __ballot(deep);
-            uint32_t first = 0;
-            if (mask) {
-                const uint32_t lane = threadIdx.x & 63;
-                if (lane == (uint32_t)__builtin_ctzll(mask)) first = atomicAdd(&dl.head[0], (uint32_t)__popcll(mask));
-                first = (uint32_t)__shfl((int)first, (int)__builtin_ctzll(mask), 64);
-            }
-            const uint32_t entry = first + wave_rank(mask, threadIdx.x & 63);
-            const bool listed = deep && entry < dl.cap;
-            if (listed) dl.pixels[entry] = local_tile * px_per_tile + i;
-            if (i < px_per_tile) dl.flags[(uint64_t)local_tile * px_per_tile + i] = listed ? 1 : 0;
+        /* one atomic per wave reserves the list entries of its deep pixels */
+        const bool deep = valid && nodes >= dl.min_nodes;
+        const uint64_t mask = __ballot(deep);
+        uint32_t first = 0;
+        if (mask) {
+            const uint32_t lane = threadIdx.x & 63;
+            if (lane == (uint32_t)__builtin_ctzll(mask)) first = atomicAdd(&dl.head[0], (uint32_t)__popcll(mask));
+            first = (uint32_t)__shfl((int)first, (int)__builtin_ctzll(mask), 64);
         }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_deepest, deepest);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t key = (RT_ORDER_KEYS - 1) - min(s_deepest, (uint32_t)(RT_ORDER_KEYS - 1)); /* key 0 = deepest */
-        ws[local_tile] = key;
+        const uint32_t entry = first + wave_rank(mask, threadIdx.x & 63);
+        const bool listed = deep && entry < dl.cap;
+        if (listed) dl.pixels[entry] = local_tile * px_per_tile + i;
+        if (i < px_per_tile) dl.flags[(uint64_t)local_tile * px_per_tile + i] = listed ? 1 : 0;
     }
 }
 
@@ -528,9 +548,12 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
     if (rp.sample0 + rp.spp == rp.spp_total) acc = acc / (float)rp.spp_total; /* image /= nsamples */
     if (has_pixel && lane == (PACK ? sub * rp.spp : 0u)) { dst[0] = in_image ? acc.x : 0.f; dst[1] = in_image ? acc.y : 0.f; dst[2] = in_image ? acc.z : 0.f; }
 #ifdef RT_WAVE_TIMES
-    if (lane == 0 && rt_dbg_times) {
-        rt_dbg_times[3ull * wave] = t_start; rt_dbg_times[3ull * wave + 1] = wall_clock64();
-        rt_dbg_times[3ull * wave + 2] = ((unsigned long long)y << 32) | x;
+    {
+        const unsigned long long wn = wave_sum(cnt.nodes), wb = wave_sum(cnt.bvh_nodes); /* of the wave: path nodes, BVH nodes fetched */
+        if (lane == 0 && rt_dbg_times) {
+            rt_dbg_times[3ull * wave] = t_start; rt_dbg_times[3ull * wave + 1] = wall_clock64();
+            rt_dbg_times[3ull * wave + 2] = (min(wb >> 6, 0xfffffull) << 44) | (min(wn, 0xfffffull) << 24) | ((unsigned long long)y << 12) | x;
+        }
     }
 #endif
     flush_counters<M>(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
@@ -751,8 +774,8 @@ struct Lib {
     uint32_t order_workers[kOrderSlots] = {};
     uint32_t order_deep_cap[kOrderSlots] = {};
     size_t order_colors_bytes[kOrderSlots] = {};
-    bool wide = true;           /* RTAMD_WIDE=0 renders every pixel with one lane per path */
-    uint32_t wide_nodes = RT_PROBE_CAP; /* RTAMD_WIDE_NODES: path nodes of the centre ray from which a pixel counts as deep */
+    int wide = 1;               /* RTAMD_WIDE: 0 = every path tree depth first, 1 = breadth-first workers where they pay, 2 = wherever something bounces */
+    uint32_t wide_nodes = 12; /* RTAMD_WIDE_NODES: path nodes of the centre ray from which a pixel counts as deep */
     unsigned order_next = 0;
     /* A ring slot is handed out again after kCamSlots / kOrderSlots further calls.  The launches that read it may
      * still be queued on another stream by then, so each slot carries an event recorded behind its last reader and
@@ -961,9 +984,9 @@ int rt_init(int device) {
     const char* ord = std::getenv("RTAMD_TILE_ORDER");
     g.order_tiles = !(ord && ord[0] == '0');
     const char* wd = std::getenv("RTAMD_WIDE");
-    g.wide = !(wd && wd[0] == '0');
+    g.wide = (wd && wd[0] >= '0' && wd[0] <= '2') ? wd[0] - '0' : 1;
     const char* wn = std::getenv("RTAMD_WIDE_NODES");
-    g.wide_nodes = RT_PROBE_CAP;
+    g.wide_nodes = 12;
     if (wn && std::atoi(wn) >= 1 && std::atoi(wn) <= RT_PROBE_CAP) g.wide_nodes = (uint32_t)std::atoi(wn);
     g.device = device;
     g.ready = true;
@@ -974,7 +997,10 @@ int rt_set_option(const char* name, int64_t value) {
     if (!name) return fail(RT_E_INVALID, "rt_set_option: null name");
     const std::string k(name);
     if (k == "tile_order") g.order_tiles = value != 0;
-    else if (k == "wide") g.wide = value != 0;
+    else if (k == "wide") {
+        if (value < 0 || value > 2) return fail(RT_E_INVALID, "rt_set_option: wide must be 0, 1 or 2");
+        g.wide = (int)value;
+    }
     else if (k == "wide_nodes") {
         if (value < 1 || value > RT_PROBE_CAP) return fail(RT_E_INVALID, "rt_set_option: wide_nodes must lie in 1 .. 24");
         g.wide_nodes = (uint32_t)value;
@@ -1370,7 +1396,15 @@ static int render_pass(bool static_mem, rt_scene_t scene, const rt_camera* cam, 
      * the probe does not see).  Deep list: the pixels whose centre ray has a tree of wide_nodes nodes or more go to
      * k_render_wide; that needs memory for their samples' colours, so not in the allocation-free call. */
     const bool want_order = g.order_tiles && r->has_bounce && !(r->mode & RT_M_BVH) && rp.n_local_tiles > 1;
-    const bool want_wide = g.wide && r->has_bounce && !static_mem;
+    /* Breadth-first workers pay where a node of a path is slow to reach -- a chain of dependent BVH fetches, or the per-ray
+     * kd traversal -- and the launch is too small to hide the waves that walk hundreds of such nodes: measured on one eighth
+     * of the 10 M-triangle frame, 16 spp per pass: 9 - 12 ms -> 7.5 ms per pass; on the many-spheres kd scene 49 -> 42 ms;
+     * but 15 -> 21 ms when the same share renders all 64 spp in one launch, and 22 -> 28 ms on the bare Cornell box, whose
+     * nodes cost a depth-first lane next to nothing.  wide = 1 applies that rule, wide = 2 uses the workers wherever
+     * something bounces. */
+    const uint64_t first_launch_waves = (uint64_t)rp.n_local_tiles * (((uint64_t)tile_w * tile_h + (spp <= 32 ? 64 / spp : 1) - 1) / (spp <= 32 ? 64 / spp : 1));
+    const bool wide_pays = (r->mode & RT_M_KD) || ((r->mode & RT_M_BVH) && first_launch_waves <= 40ull * 4096ull);
+    const bool want_wide = r->has_bounce && !static_mem && (g.wide == 2 || (g.wide == 1 && wide_pays));
     if (want_order || want_wide) {
         uint32_t* ws = nullptr;
         bool fresh = true;

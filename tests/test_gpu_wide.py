@@ -1,6 +1,6 @@
-"""Pixels with deep path trees are rendered by k_render_wide (several lanes per path, a list of deep pixels, per-sample
-colours summed afterwards).  That is scheduling only: with it forced on for every pixel whose tree has a second node
-(wide_nodes = 2), left at its default, or switched off, a render gives the same floats and the same work counters --
+"""Pixels with deep path trees are rendered by worker waves that expand the trees breadth first (a list of deep pixels,
+per-sample colours summed afterwards).  That is scheduling only: with it forced on for every pixel whose tree has a second
+node (wide = 2, wide_nodes = 2), for fewer pixels, or switched off, a render gives the same floats and the same work counters --
 for every kernel variant (root-leaf scenes, kd-tree with internal nodes, triangle BVH, both), one-shot and in passes.
 The list holds at most a quarter of the pixels: on the small images here it overflows, which is covered too.
 Run with -m gpu."""
@@ -19,7 +19,7 @@ def device():
     api.init(0)
     yield
     api.set_option("wide", 1)
-    api.set_option("wide_nodes", 24)
+    api.set_option("wide_nodes", 12)
 
 
 def _scenes():
@@ -52,7 +52,7 @@ def test_wide_rendering_changes_no_float():
         api.set_option("wide", 0)
         ref = _render_all(g, cam, w, h, cases)
         for nodes in (2, 6, 24):
-            api.set_option("wide", 1)
+            api.set_option("wide", 2)
             api.set_option("wide_nodes", nodes)
             got = _render_all(g, cam, w, h, cases)
             for (a, sa), (b, sb), case in zip(ref, got, cases):

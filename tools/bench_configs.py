@@ -68,7 +68,7 @@ if a.wave_times:
         print(f"rank {rank}: {len(t)} waves, launch span {en.max():.0f} us, sum of wave times / 4096 slots {dur.sum() / 4096:.0f} us, "
               f"mean wave {dur.mean():.1f} us, max {dur.max():.0f} us; percentiles 50/90/99/99.9: {[round(float(np.percentile(dur, q))) for q in (50, 90, 99, 99.9)]}")
         for i in np.argsort(-en)[:10]:
-            print(f"   ends {en[i]:.0f} us  started {st[i]:.0f} us  ran {dur[i]:.0f} us  pixel ({t[i, 2] & 0xffffffff}, {t[i, 2] >> 32})")
+            print(f"   ends {en[i]:.0f} us  started {st[i]:.0f} us  ran {dur[i]:.0f} us  pixel ({t[i, 2] & 0xfff}, {(t[i, 2] >> 12) & 0xfff}) path nodes {(t[i, 2] >> 24) & 0xfffff} BVH nodes {((t[i, 2] >> 44) & 0xfffff) * 64}")
     scene.close()
     sys.exit(0)
 worst = 0.0

@@ -12,7 +12,8 @@ from raytracing_amd import api, host, parallel_render  # noqa: E402
 api.init(0)
 dev = torch.device("cuda", 0)
 scene = host.HostScene.builtin(2).upload()
-w, h, spp, tw, th = 1920, 1080, 64, 16, 16
+tw = th = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+w, h, spp = 1920, 1080, 64
 cam = host.camera_default(w, h)
 for world in (1, 2, 4, 8, 8, 8):
     lay = parallel_render.TileLayout(w, h, tw, th, world)

@@ -34,7 +34,7 @@ for rank in (0, 6):
     dur = en - st
     print(f"rank {rank}: waves {len(t)}, launch span {en.max():.0f} us, mean wave {dur.mean():.1f} us, max wave {dur.max():.0f} us")
     for i in np.argsort(-en)[:8]:
-        print(f"   ends {en[i]:.0f} us  started {st[i]:.0f} us  ran {dur[i]:.0f} us  pixel ({t[i, 2] & 0xffffffff}, {t[i, 2] >> 32}) slot {widx[i] // 256}")
+        print(f"   ends {en[i]:.0f} us  started {st[i]:.0f} us  ran {dur[i]:.0f} us  pixel ({t[i, 2] & 0xfff}, {(t[i, 2] >> 12) & 0xfff}) path nodes {(t[i, 2] >> 24) & 0xfffff} BVH nodes {((t[i, 2] >> 44) & 0xfffff) * 64} slot {widx[i] // 256}")
     print("   wave duration percentiles 50/90/99/99.9:", [round(float(np.percentile(dur, p)), 0) for p in (50, 90, 99, 99.9)])
     slow = dur > 500
     print("   slots of waves > 0.5 ms: min", (widx[slow] // 256).min(), "max", (widx[slow] // 256).max(), "distinct", len(set(widx[slow] // 256)))
