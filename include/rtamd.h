@@ -221,6 +221,7 @@ int rt_scene_destroy(rt_scene_t scene);
  * RT_BUILD_AUTO_DEVICE_TRIANGLES triangles and rt_scene_create_ex(desc, RT_BUILD_BVH_DEVICE, out) from there
  * on; the environment variable RTAMD_BVH_BUILD=host|device overrides that choice. */
 #define RT_BUILD_AUTO_DEVICE_TRIANGLES (1u << 20)
+#define RT_MAX_TRIANGLES (1u << 28) /* triangles per scene: RT_E_LIMIT from there on */
 #define RT_BUILD_BVH_DEVICE 1u
 int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* out);
 
@@ -267,6 +268,13 @@ void rt_normalize_dirs(const float* dir, size_t n, float* out);
 /* ---- batch Mesh::intersect (R/src/Mesh.h:206-281) of mesh `mesh` alone: exposes tIndex ------ */
 int rt_mesh_intersect(rt_scene_t scene, uint32_t mesh, const float* org, const float* dir,
                       size_t n, rt_hit* out);
+
+/* ---- one object's own intersect routine: Sphere::intersect (R/src/Sphere.h:85-162), Square::intersect
+ * (R/src/Square.h:63-115), Mesh::intersect (type RT_MESH = rt_mesh_intersect) -- without the scene's root box and
+ * without the other objects.  hit / t / p / n as those routines leave them; Sphere's secondintersection, which nothing
+ * in the reference reads, is not returned. */
+int rt_primitive_intersect(rt_scene_t scene, int type, uint32_t object, const float* org, const float* dir,
+                           size_t n, rt_hit* out);
 
 /* ---- primary rays: screen_space_to_world_space_ray (R/src/matrixUtilities.h:218-222) --------
  * u, v: n floats each; org/dir: 3*n floats out (dir normalised once, as that function leaves it). */
@@ -338,6 +346,27 @@ void rt_counters_total(const uint64_t* h_counters, uint64_t out[RT_COUNTER_FIELD
  * into a row-major w*h*3 image.  Host helper for the gather step. */
 int rt_tiles_to_image(const float* gathered, uint32_t w, uint32_t h, uint32_t tile_w,
                       uint32_t tile_h, uint32_t world, float* rgb_image);
+
+/* ---- several GPUs: one process per GPU, tiles gathered with RCCL over xGMI ----------------------------------------
+ * No reference counterpart (the reference is one thread on one CPU).  Each process calls rt_init(its GPU); one of them
+ * makes an id (rt_comm_unique_id) and hands its RT_COMM_ID_BYTES bytes to the others by any means (a file, a pipe,
+ * MPI); all call rt_comm_init(id, rank, world) together.  RCCL is opened at run time by the first of these calls.
+ * rt_render_sharded: every rank renders the tiles t with t % world == rank (as rt_render(.., rank, world, ..)), the
+ * tile buffers go to rank 0 in one group of point-to-point transfers (a receive per peer on rank 0, a send on the
+ * others: seven distinct xGMI links into rank 0 on an 8-GPU node), and rank 0 gets the row-major w*h*3 float image;
+ * rgb_image is ignored on the other ranks.  stats describe this rank's share.  Without a communicator it renders the
+ * whole image (rank 0 of 1).  Collective: all ranks call it with the same arguments.
+ * rt_gather_tiles_device is that exchange alone for callers that keep their own device buffers: floats_per_rank floats
+ * of every rank arrive rank-major in d_gathered on `root` (its own part copied), enqueued on hip_stream. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]);
+int rt_comm_init(const char id[RT_COMM_ID_BYTES], int rank, int world);
+int rt_comm_destroy(void);
+int rt_comm_rank(void);
+int rt_comm_world(void);
+int rt_gather_tiles_device(const float* d_mine, size_t floats_per_rank, float* d_gathered, int root, void* hip_stream);
+int rt_render_sharded(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed,
+                      uint32_t tile_w, uint32_t tile_h, float* rgb_image, rt_stats* stats);
 
 /* ---- image output (R/main.cpp:204-216) ------------------------------------------------------
  * rt_tiles_to_rgb8_device: what rt_tiles_to_image does, on the device and fused with the reference's

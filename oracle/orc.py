@@ -104,6 +104,7 @@ def lib():
         L.orc_intersect_mt.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int]
         L.orc_render_pixels.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t,
                                         C.c_int, vp, C.POINTER(Stats)]
+        L.orc_primitive_intersect.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_size_t, vp]
         L.orc_mesh_intersect.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, vp]
         L.orc_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(Stats)]
         L.orc_render.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
@@ -181,6 +182,14 @@ class Scene:
         st = Stats()
         lib().orc_render_pixels(self.h, C.byref(cam), w, h, spp, seed, _ptr(pixels), len(pixels), threads, _ptr(rgb), C.byref(st))
         return rgb, st
+
+    def primitive_intersect(self, type_, obj, org, dirs):
+        """Sphere::intersect (type 1) / Square::intersect (type 2) of object `obj` alone."""
+        org, dirs = _f32(org), _f32(dirs)
+        n = org.shape[0]
+        out = np.zeros(n, HIT_DTYPE)
+        lib().orc_primitive_intersect(self.h, type_, obj, _ptr(org), _ptr(dirs), n, _ptr(out))
+        return out
 
     def mesh_intersect(self, mesh, org, dirs):
         org, dirs = _f32(org), _f32(dirs)

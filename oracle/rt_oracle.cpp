@@ -1015,6 +1015,19 @@ void orc_mesh_intersect(orc_scene* h, uint32_t mesh, const float* org, const flo
     }
 }
 
+/* Sphere::intersect (R/src/Sphere.h:85-162) / Square::intersect (R/src/Square.h:63-115) of one object alone */
+void orc_primitive_intersect(orc_scene* h, int type, uint32_t object, const float* org, const float* dir, size_t n, rt_hit* out) {
+    Counters c;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r = Ray::stored(from3(org + 3 * i), from3(dir + 3 * i));
+        Hit hit;
+        bool ok = type == RT_SPHERE ? sphere_hit(h->s.spheres[object], r, hit, c) : square_hit(h->s.squares[object], r, hit, c);
+        if (ok) { hit.type = type; hit.object = (int)object; }
+        else hit = Hit();
+        fill_hit(out[i], hit);
+    }
+}
+
 void orc_trace(orc_scene* h, const float* org, const float* dir, size_t n, const uint32_t* pixel, const uint32_t* sample,
                uint32_t seed, uint32_t k0, float* rgb, rt_stats* stats) {
     Counters c;

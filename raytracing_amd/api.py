@@ -80,7 +80,8 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
 
 # every symbol include/rtamd.h declares
 EXPORTS = ["rt_init", "rt_set_option", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_destroy", "rt_scene_kdtree",
-           "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_generate_rays", "rt_trace",
+           "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_primitive_intersect", "rt_comm_unique_id", "rt_comm_init",
+           "rt_comm_destroy", "rt_comm_rank", "rt_comm_world", "rt_gather_tiles_device", "rt_render_sharded", "rt_generate_rays", "rt_trace",
            "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_render_device_noalloc", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
 _lib = None
@@ -107,6 +108,11 @@ def lib():
         L.rt_intersect.argtypes = [u64, vp, vp, C.c_size_t, vp]
         L.rt_intersect_device.argtypes = [u64, vp, vp, C.c_size_t, vp, vp]
         L.rt_mesh_intersect.argtypes = [u64, u32, vp, vp, C.c_size_t, vp]
+        L.rt_primitive_intersect.argtypes = [u64, C.c_int, u32, vp, vp, C.c_size_t, vp]
+        L.rt_comm_unique_id.argtypes = [vp]
+        L.rt_comm_init.argtypes = [vp, C.c_int, C.c_int]
+        L.rt_gather_tiles_device.argtypes = [vp, C.c_size_t, vp, C.c_int, vp]
+        L.rt_render_sharded.argtypes = [u64, C.POINTER(Camera)] + [u32] * 6 + [vp, C.POINTER(Stats)]
         L.rt_generate_rays.argtypes = [C.POINTER(Camera), vp, vp, C.c_size_t, vp, vp]
         L.rt_trace.argtypes = [u64, vp, vp, C.c_size_t, vp, vp, u32, u32, vp, C.POINTER(Stats)]
         L.rt_tiles_per_rank.restype = C.c_size_t
@@ -136,6 +142,25 @@ def init(device=0):
 def set_option(name, value):
     """rt_set_option: scheduling switches ("tile_order", "wide", "wide_nodes"); results never depend on them."""
     check(lib().rt_set_option(name.encode(), int(value)))
+
+
+def comm_unique_id():
+    """128 bytes naming a new communicator (made by one process, handed to the others)."""
+    buf = C.create_string_buffer(128)
+    check(lib().rt_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(id_bytes, rank, world):
+    check(lib().rt_comm_init(C.create_string_buffer(bytes(id_bytes), 128), rank, world))
+
+
+def comm_destroy():
+    check(lib().rt_comm_destroy())
+
+
+def gather_tiles_device(d_mine_ptr, floats_per_rank, d_gathered_ptr, root, stream_ptr):
+    check(lib().rt_gather_tiles_device(C.c_void_p(d_mine_ptr), floats_per_rank, C.c_void_p(d_gathered_ptr), root, C.c_void_p(stream_ptr)))
 
 
 def shutdown():
@@ -211,6 +236,22 @@ class DeviceScene:
         out = np.zeros(n, HIT_DTYPE)
         check(lib().rt_mesh_intersect(self.h, mesh, _ptr(org), _ptr(dirs), n, _ptr(out)))
         return out
+
+    def primitive_intersect(self, type_, obj, org, dirs):
+        """rt_primitive_intersect: Sphere::intersect / Square::intersect / Mesh::intersect of one object alone."""
+        org, dirs = _f32(org), _f32(dirs)
+        n = org.shape[0]
+        out = np.zeros(n, HIT_DTYPE)
+        check(lib().rt_primitive_intersect(self.h, type_, obj, _ptr(org), _ptr(dirs), n, _ptr(out)))
+        return out
+
+    def render_sharded(self, cam, w, h, spp, seed=1, tile_w=16, tile_h=16):
+        """rt_render_sharded: collective over the processes of the communicator (rank 0 of 1 without one); (h, w, 3) on rank 0."""
+        cam = cam if isinstance(cam, Camera) else copy_struct(Camera, cam)
+        img = np.zeros((h, w, 3), np.float32)
+        st = Stats()
+        check(lib().rt_render_sharded(self.h, C.byref(cam), w, h, spp, seed, tile_w, tile_h, _ptr(img), C.byref(st)))
+        return img, st
 
     def trace(self, org, dirs, pixel, sample, seed=1, k0=2):
         org, dirs = _f32(org), _f32(dirs)

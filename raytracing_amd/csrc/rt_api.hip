@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "rt_build.h"
+#include "rt_comm.h"
 #include "rt_bvh_device.h"
 #include "rt_device.h"
 
@@ -628,6 +629,20 @@ __global__ __launch_bounds__(256) void k_mesh_intersect(DeviceScene sc, uint32_t
     out[i] = pack_hit(h, RT_MESH, (int)mesh, h.hit ? (int)ldc(&sc.tri_orig[h.tri]) : -1, rec.u, rec.v);
 }
 
+/* Sphere::intersect (R/src/Sphere.h:85-162) / Square::intersect (R/src/Square.h:63-115) of one object alone: no root box,
+ * no other object. */
+__global__ __launch_bounds__(256) void k_prim_intersect(DeviceScene sc, int type, uint32_t object, const float* __restrict__ org,
+                                                       const float* __restrict__ dir, size_t n, rt_hit* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
+    HitRec rec; rec.type = -1; rec.obj = (int)object; rec.tri = -1; rec.u = rec.v = 0.f; rec.t = RT_INF;
+    float t;
+    if (type == RT_SPHERE ? sphere_t(ldc(&sc.spheres[object]), o, d, t) : square_t(ldc(&sc.squares[object]), o, d, t)) { rec.type = type; rec.t = t; }
+    FullHit h = finish_hit(sc, rec, o, d);
+    out[i] = pack_hit(h, type, (int)object, -1, 0.f, 0.f);
+}
+
 template <int M>
 __global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
                                                const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
@@ -1011,6 +1026,7 @@ int rt_set_option(const char* name, int64_t value) {
 
 int rt_shutdown(void) {
     if (!g.ready) return RT_OK;
+    rtc::destroy();
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     for (auto& kv : g.scenes) release(kv.second);
@@ -1052,6 +1068,7 @@ int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches) {
 int rt_scene_check(const rt_scene_desc* desc, rt_build_info* info) {
     if (!desc || !info) return fail(RT_E_INVALID, "rt_scene_check: null argument");
     std::memset(info, 0, sizeof(*info));
+    if (desc->n_triangles >= RT_MAX_TRIANGLES) return fail(RT_E_LIMIT, "rt_scene_check: 2^28 triangles or more (BVH leaf entries hold a 28-bit triangle position)");
     rtb::Built b;
     std::string err;
     if (!rtb::build_scene(*desc, b, err)) return fail(RT_E_INVALID, err);
@@ -1074,6 +1091,7 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
     if (!g.ready) return fail(RT_E_NOINIT, "rt_scene_create: call rt_init first");
     if (!desc || !out) return fail(RT_E_INVALID, "rt_scene_create: null argument");
     if (flags & ~(uint32_t)RT_BUILD_BVH_DEVICE) return fail(RT_E_INVALID, "rt_scene_create_ex: unknown flag");
+    if (desc->n_triangles >= RT_MAX_TRIANGLES) return fail(RT_E_LIMIT, "rt_scene_create: 2^28 triangles or more (BVH leaf entries hold a 28-bit triangle position)");
     HIP_TRY(hipSetDevice(g.device));
     const bool device_bvh = (flags & RT_BUILD_BVH_DEVICE) != 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1124,6 +1142,13 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
     rt_scene_t h = g.next_handle++;
     g.scenes[h] = r;
     *out = h;
+    /* RTAMD_VERIFY_BUILD=1: read the tables back and run the host verifier on them before the scene is handed out
+     * (every triangle in one leaf, boxes nested, depth within the traversal stack) -- what rt_scene_verify does on request */
+    const char* vb = std::getenv("RTAMD_VERIFY_BUILD");
+    if (vb && vb[0] == '1' && r->n_bvh) {
+        const int rc_verify = rt_scene_verify(h, nullptr, nullptr);
+        if (rc_verify) { const std::string why = g.error; (void)rt_scene_destroy(h); *out = 0; return fail(rc_verify, "rt_scene_create: built tree rejected: " + why); }
+    }
     return RT_OK;
 }
 
@@ -1249,6 +1274,30 @@ int rt_mesh_intersect(rt_scene_t scene, uint32_t mesh, const float* org, const f
     HIP_TRY(hipMemcpyAsync(d_d, dir, 12 * n, hipMemcpyHostToDevice, g.stream));
     hipLaunchKernelGGL(k_mesh_intersect, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, mesh, (const float*)d_o,
                        (const float*)d_d, n, (rt_hit*)d_h);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_h, sizeof(rt_hit) * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RT_OK;
+}
+
+int rt_primitive_intersect(rt_scene_t scene, int type, uint32_t object, const float* org, const float* dir, size_t n, rt_hit* out) {
+    if (type == RT_MESH) return rt_mesh_intersect(scene, object, org, dir, n, out);
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_primitive_intersect: call rt_init first");
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_primitive_intersect: unknown scene");
+    if (type != RT_SPHERE && type != RT_SQUARE) return fail(RT_E_INVALID, "rt_primitive_intersect: type must be RT_MESH, RT_SPHERE or RT_SQUARE");
+    if (object >= (type == RT_SPHERE ? r->dev.n_spheres : r->dev.n_squares)) return fail(RT_E_INVALID, "rt_primitive_intersect: no such object");
+    if (n == 0) return RT_OK;
+    if (!org || !dir || !out) return fail(RT_E_INVALID, "rt_primitive_intersect: null buffer");
+    HIP_TRY(hipSetDevice(g.device));
+    Scratch tmp;
+    void *d_o, *d_d, *d_h;
+    int rc;
+    if ((rc = tmp.get(&d_o, 12 * n)) || (rc = tmp.get(&d_d, 12 * n)) || (rc = tmp.get(&d_h, sizeof(rt_hit) * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_o, org, 12 * n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_d, dir, 12 * n, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_prim_intersect, dim3(blocks_for(n)), dim3(256), 0, g.stream, r->dev, type, object, (const float*)d_o, (const float*)d_d, n,
+                       (rt_hit*)d_h);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_h, sizeof(rt_hit) * n, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -1532,6 +1581,85 @@ int rt_render(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, ui
     HIP_TRY(hipStreamSynchronize(g.stream));
     rt_counters_total(slots.data(), cnt);
     if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
+        stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4]; stats->rays_skipped = cnt[5];
+    }
+    return RT_OK;
+}
+
+/* ---- multi-GPU: one process per GPU, RCCL point-to-point gather ------------------------------------------- */
+int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]) {
+    if (!id) return fail(RT_E_INVALID, "rt_comm_unique_id: null buffer");
+    std::string err;
+    if (!rtc::unique_id(id, err)) return fail(RT_E_HIP, "rt_comm_unique_id: " + err);
+    return RT_OK;
+}
+
+int rt_comm_init(const char id[RT_COMM_ID_BYTES], int rank, int world) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_comm_init: call rt_init first");
+    if (!id) return fail(RT_E_INVALID, "rt_comm_init: null id");
+    HIP_TRY(hipSetDevice(g.device));
+    std::string err;
+    if (!rtc::init(id, rank, world, err)) return fail(RT_E_INVALID, "rt_comm_init: " + err);
+    return RT_OK;
+}
+
+int rt_comm_destroy(void) {
+    if (g.ready) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+    rtc::destroy();
+    return RT_OK;
+}
+
+int rt_comm_rank(void) { return rtc::rank(); }
+int rt_comm_world(void) { return rtc::world(); }
+
+int rt_gather_tiles_device(const float* d_mine, size_t floats_per_rank, float* d_gathered, int root, void* hip_stream) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_gather_tiles_device: call rt_init first");
+    if (!rtc::active()) return fail(RT_E_NOINIT, "rt_gather_tiles_device: call rt_comm_init first");
+    if (!d_mine || (rtc::rank() == root && !d_gathered)) return fail(RT_E_INVALID, "rt_gather_tiles_device: null buffer");
+    std::string err;
+    if (!rtc::gather(d_mine, floats_per_rank, d_gathered, root, (hipStream_t)hip_stream, err)) return fail(RT_E_HIP, "rt_gather_tiles_device: " + err);
+    return RT_OK;
+}
+
+int rt_render_sharded(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w, uint32_t tile_h,
+                      float* rgb_image, rt_stats* stats) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_render_sharded: call rt_init first");
+    const int rank = rtc::rank(), world = rtc::world(); /* 0 / 1 without a communicator */
+    if (rank == 0 && !rgb_image) return fail(RT_E_INVALID, "rt_render_sharded: rank 0 needs the image buffer");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    HIP_TRY(hipSetDevice(g.device));
+    /* every rank's buffer has the size of rank 0's, the largest: the gathered block is regular */
+    const size_t per_rank = rt_tiles_per_rank(w, h, tile_w, tile_h, 0, (uint32_t)world) * tile_w * tile_h * 3;
+    if (per_rank == 0) return fail(RT_E_INVALID, "rt_render_sharded: zero size");
+    Scratch tmp;
+    void *d_mine, *d_all = nullptr, *d_cnt;
+    int rc;
+    if ((rc = tmp.get(&d_mine, per_rank * 4)) || (rc = tmp.get(&d_cnt, RT_COUNTER_WORDS * 8))) return rc;
+    if (rank == 0 && (rc = tmp.get(&d_all, per_rank * 4 * (size_t)world))) return rc;
+    HIP_TRY(hipMemsetAsync(d_mine, 0, per_rank * 4, g.stream));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, RT_COUNTER_WORDS * 8, g.stream));
+    HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    if ((rc = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, (uint32_t)rank, (uint32_t)world, (float*)d_mine, (uint64_t*)d_cnt, g.stream))) return rc;
+    HIP_TRY(hipEventRecord(g.ev1, g.stream));
+    if (world > 1) {
+        std::string err;
+        if (!rtc::gather((const float*)d_mine, per_rank, (float*)d_all, 0, g.stream, err)) return fail(RT_E_HIP, "rt_render_sharded: " + err);
+    }
+    std::vector<uint64_t> slots(RT_COUNTER_WORDS);
+    HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
+    std::vector<float> gathered;
+    if (rank == 0) {
+        gathered.resize(per_rank * (size_t)world);
+        HIP_TRY(hipMemcpyAsync(gathered.data(), world > 1 ? d_all : d_mine, gathered.size() * 4, hipMemcpyDeviceToHost, g.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (rank == 0 && (rc = rt_tiles_to_image(gathered.data(), w, h, tile_w, tile_h, (uint32_t)world, rgb_image))) return rc;
+    if (stats) { /* this rank's share */
+        uint64_t cnt[RT_COUNTER_FIELDS];
+        rt_counters_total(slots.data(), cnt);
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
         stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;

@@ -72,6 +72,18 @@ public:
         for (size_t i = 0; i < vertices.size(); ++i) vertices[i].position = Vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
         for (size_t i = 0; i < triangles.size(); ++i)
             for (unsigned int j = 0; j < 3; ++j) triangles[i].v[j] = idx[3 * i + j];
+        check_indices(filename);
+    }
+
+    /* A face that names a vertex the file does not have would make recomputeNormals and every later pass read and write
+     * outside the vertex array: refuse the file the way a missing one is refused (R/src/Mesh.cpp:23-24). */
+    void check_indices(const std::string& filename) const {
+        for (size_t i = 0; i < triangles.size(); ++i)
+            for (unsigned int j = 0; j < 3; ++j)
+                if (triangles[i].v[j] >= vertices.size()) {
+                    std::cerr << filename << ": face " << i << " refers to vertex " << triangles[i].v[j] << " of " << vertices.size() << std::endl;
+                    exit(EXIT_FAILURE);
+                }
     }
 
     /* The reference's reader, token by token (the corner count of a face is read and ignored, three indices
@@ -98,6 +110,7 @@ public:
             for (unsigned int j = 0; j < 3; ++j) in >> triangles[i].v[j];
             if (coloured) in.ignore(rest, '\n');
         }
+        check_indices(filename);
     }
 
     void recomputeNormals() { /* R/src/Mesh.cpp:41-54: unit face normals summed per vertex */

@@ -47,6 +47,8 @@ inline void ray_trace_from_camera(Scene& scene, Camera& camera, unsigned nsample
     std::vector<Vec3> image;
     rt_stats st{};
     scene.render(camera.glState(), w, h, nsamples, seed, image, &st);
+    if (stats_out) *stats_out = st;
+    if (rt_comm_rank() != 0) return; /* several processes, one per GPU: rank 0 has the image and writes it */
     std::cout << "\rProgress: 100% - Done!            " << std::endl;
     if (!write_ppm_p3(filename, image, w, h)) return;
     if (!filename_p6.empty() && !write_ppm_p6(filename_p6, image, w, h)) return;

@@ -278,12 +278,14 @@ public:
         for (size_t i = 0; i < n; ++i) out[i] = Vec3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
     }
     /* whole image, row-major w*h Vec3 (R/main.cpp:182-194 without the loop) */
+    /* With a communicator (rt_comm_init, see rt_main --gpus) this is a collective call: every process renders its tiles
+     * and rank 0 receives the image; the other ranks get an empty one. */
     void render(const rt_camera& cam, unsigned w, unsigned h, unsigned spp, uint32_t seed, std::vector<Vec3>& image, rt_stats* stats = nullptr) {
         const uint32_t tw = 16, th = 16;
-        size_t tiles = rt_tiles_per_rank(w, h, tw, th, 0, 1);
-        std::vector<float> buf(tiles * tw * th * 3), img((size_t)w * h * 3);
-        rthost::require(rt_render(deviceHandle(), &cam, w, h, spp, seed, tw, th, 0, 1, buf.data(), stats), "rt_render");
-        rthost::require(rt_tiles_to_image(buf.data(), w, h, tw, th, 1, img.data()), "rt_tiles_to_image");
+        const bool root = rt_comm_rank() == 0;
+        std::vector<float> img(root ? (size_t)w * h * 3 : 0);
+        rthost::require(rt_render_sharded(deviceHandle(), &cam, w, h, spp, seed, tw, th, root ? img.data() : nullptr, stats), "rt_render_sharded");
+        if (!root) { image.clear(); return; }
         image.resize((size_t)w * h);
         for (size_t i = 0; i < image.size(); ++i) image[i] = Vec3(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
     }

@@ -3,7 +3,7 @@
  *   Scene::computeIntersection(Ray), Scene::rayTrace(Ray) (with its counter-RNG sample context),
  *   Mesh::intersect(Ray), and the batch forms behind them.
  * usage: api_check <scene 0..3> <star.off> <rays.txt>     rays.txt: "ox oy oz dx dy dz pixel sample" per line
- * output per ray: hit type object t px py pz nx ny nz | r g b | mesh: hit tIndex t   (hex floats) */
+ * output per ray: hit type object t px py pz nx ny nz | r g b | mesh: hit tIndex t [| S hit t p n] [| Q hit t p n]   (hex floats) */
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -43,6 +43,17 @@ int main(int argc, char** argv) {
         if (!scene.getMeshes().empty()) {
             RayTriangleIntersection m = scene.getMeshes()[0].intersect(ray);
             std::printf(" | %d %d %a %a %a %a", m.intersectionExists ? 1 : 0, (int)m.tIndex, m.t, m.w0, m.w1, m.w2);
+        }
+        /* the objects' own routines: Sphere::intersect / Square::intersect of object 0 (prefix S / Q) */
+        if (!scene.getSpheres().empty()) {
+            RaySphereIntersection q = scene.getSpheres()[0].intersect(ray);
+            std::printf(" | S %d %a %a %a %a %a %a %a", q.intersectionExists ? 1 : 0, q.t, q.intersection[0], q.intersection[1], q.intersection[2],
+                        q.normal[0], q.normal[1], q.normal[2]);
+        }
+        if (!scene.getSquares().empty()) {
+            RaySquareIntersection q = scene.getSquares()[0].intersect(ray);
+            std::printf(" | Q %d %a %a %a %a %a %a %a", q.intersectionExists ? 1 : 0, q.t, q.intersection[0], q.intersection[1], q.intersection[2],
+                        q.normal[0], q.normal[1], q.normal[2]);
         }
         std::printf("\n");
     }

@@ -40,6 +40,8 @@ def test_single_ray_calls_match_oracle(sid, tmp_path):
     hits = o.intersect(org, du)
     cols, _ = o.trace(org, du, pix, smp, seed=1, k0=2)
     mh = o.mesh_intersect(0, org, du) if sid == 3 else None
+    own = {"S": o.primitive_intersect(1, 0, org, du) if o.desc.n_spheres else None,
+           "Q": o.primitive_intersect(2, 0, org, du) if o.desc.n_squares else None}
     for i, ln in enumerate(lines):
         parts = [p.split() for p in ln.split("|")]
         a = parts[0]
@@ -57,6 +59,46 @@ def test_single_ray_calls_match_oracle(sid, tmp_path):
                 assert int(m[1]) == mh["tri"][i] and _hexf(m[2]).tobytes() == mh["t"][i].tobytes()
                 w = np.array([_hexf(t) for t in m[3:6]], np.float32)
                 assert w[1].tobytes() == mh["u"][i].tobytes() and w[2].tobytes() == mh["v"][i].tobytes()
+        for part in parts[2:]:   # Sphere::intersect / Square::intersect of object 0 alone
+            if part[0] in own:
+                want = own[part[0]]
+                assert want is not None and int(part[1]) == want["hit"][i]
+                if want["hit"][i]:
+                    got = np.array([_hexf(t) for t in part[2:9]], np.float32)
+                    ref = np.concatenate([[want["t"][i]], want["p"][i], want["n"][i]]).astype(np.float32)
+                    assert got.tobytes() == ref.tobytes(), (part[0], i)
+        assert sum(1 for part in parts[2:] if part[0] in own) == sum(v is not None for v in own.values())
+
+
+def test_primitive_intersect_and_sharded_render_of_one_rank():
+    """rt_primitive_intersect over many rays against the oracle's Sphere::intersect / Square::intersect, bit for bit (rays
+    from inside the sphere, tangent ones, rays in the square's plane); rt_render_sharded with a one-rank RCCL communicator
+    (rt_comm_unique_id / rt_comm_init: the library opens RCCL) gives the image of rt_render."""
+    from raytracing_amd import api
+    api.init(0)
+    o = orc.Scene.builtin(2)
+    g = api.DeviceScene(o.desc, keep=o)
+    org, d = rayset.mixed(orc, n_each=3000)
+    for type_, n_obj in ((1, o.desc.n_spheres), (2, o.desc.n_squares)):
+        for obj in range(n_obj):
+            a, b = o.primitive_intersect(type_, obj, org, d), g.primitive_intersect(type_, obj, org, d)
+            assert a["hit"].sum() > 50
+            assert a.tobytes() == b.tobytes(), (type_, obj)
+    with pytest.raises(api.RtError):
+        g.primitive_intersect(1, 99, org, d)
+    w, h, spp = 100, 37, 3
+    cam = orc.camera_default(w, h)
+    want, st = g.render(cam, w, h, spp, seed=9, tile_w=16, tile_h=8)
+    got, st0 = g.render_sharded(cam, w, h, spp, seed=9, tile_w=16, tile_h=8)      # no communicator: rank 0 of 1
+    assert got.tobytes() == want.tobytes() and st0.rays == st.rays
+    api.comm_init(api.comm_unique_id(), 0, 1)
+    try:
+        assert api.lib().rt_comm_world() == 1 and api.lib().rt_comm_rank() == 0
+        got, st1 = g.render_sharded(cam, w, h, spp, seed=9, tile_w=16, tile_h=8)
+        assert got.tobytes() == want.tobytes() and st1.rays == st.rays
+    finally:
+        api.comm_destroy()
+    g.close()
 
 
 def test_headless_plus_and_r_keys(tmp_path):
@@ -64,7 +106,7 @@ def test_headless_plus_and_r_keys(tmp_path):
     of that scene under the counter RNG (up to the rare pixel whose colour sits on a quantisation step)."""
     out = tmp_path / "rendu.ppm"
     w, h, spp = 96, 80, 3
-    subprocess.run([os.path.join(HOST_DIR, "rt_main"), "--w", str(w), "--h", str(h), "--spp", str(spp), "--seed", "1", "--keys", "+r",
+    subprocess.run([os.path.join(HOST_DIR, "rt_main"), "--w", str(w), "--h", str(h), "--spp", str(spp), "--seed", "1", "--scene", "2", "--keys", "+r",
                     "--out", str(out), "--p6", str(tmp_path / "rendu_p6.ppm"), "--off", host.STAR_OFF], check=True, capture_output=True,
                    timeout=300)
     toks = open(out).read().split()

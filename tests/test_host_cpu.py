@@ -192,3 +192,26 @@ def test_fast_off_reader_declines_what_it_cannot_reproduce(tmp_path, case):
     _write_off(p, v, faces, tag=tag, nv=nv, nt=nt)
     same, fast, _, _ = host.off_compare(str(p))
     assert same and not fast
+
+
+def test_off_file_with_an_out_of_range_face_index_is_refused(tmp_path):
+    """A face that names a vertex the file does not have is refused when the file is read (message + failure exit, the
+    reference's convention for an unusable mesh file) -- before recomputeNormals could write outside the vertex array and
+    before anything touches a GPU.  Both readers: the multi-threaded one and the token reader (COFF input)."""
+    import subprocess
+    rt_main = os.path.join(os.path.dirname(os.path.abspath(host.__file__)), "host", "rt_main")
+    for tag, extra in (("OFF", ""), ("COFF", " 255 0 0 255")):
+        bad = tmp_path / f"bad_{tag}.off"
+        bad.write_text(f"{tag}\n4 2 0\n" + "".join(f"{x} {y} 0{extra}\n" for x, y in ((0, 0), (1, 0), (1, 1), (0, 1))) + "3 0 1 2\n3 0 2 7\n")
+        r = subprocess.run([rt_main, "--keys", "", "--off", str(bad)], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "refers to vertex 7 of 4" in r.stderr, (tag, r.returncode, r.stderr)
+
+
+def test_triangle_count_limit():
+    """2^28 triangles or more are refused with RT_E_LIMIT before anything is read (BVH leaf entries hold 28-bit positions)."""
+    d = api.SceneDesc()
+    d.n_triangles = 1 << 28
+    d.kd_max_depth, d.kd_max_leaf, d.kd_epsilon = 15, 30, 0.01
+    with pytest.raises(api.RtError) as e:
+        api.scene_check(d)
+    assert e.value.code == -5
