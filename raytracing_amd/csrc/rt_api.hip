@@ -643,18 +643,24 @@ __global__ __launch_bounds__(256) void k_prim_intersect(DeviceScene sc, int type
     out[i] = pack_hit(h, type, (int)object, -1, 0.f, 0.f);
 }
 
+#ifndef RT_KTRACE_WAVES
+#define RT_KTRACE_WAVES 4
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_KTRACE_WAVES, RT_KTRACE_WAVES))) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
                                                const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
+    /* as in k_render: 4 waves per SIMD, and the first levels of the path-frame stack in LDS where no BVH stack needs it */
+    constexpr int L = (M & RT_M_BVH) ? 0 : RT_FRAME_LDS;
+    __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 256 : 1];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
+    Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE, s_frames + (L ? threadIdx.x : 0), 256);
     uint32_t smp = 0;
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
         Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
-        f3 c = trace_path<M>(sc, o, d, rng, cnt);
+        f3 c = trace_path<M, false, L>(sc, o, d, rng, cnt);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
         smp = 1;
     }

@@ -173,7 +173,7 @@ def test_fast_off_reader_gives_the_token_readers_values(tmp_path):
     assert host.off_compare(str(p2)) == (True, True, 40000, 80000)
 
 
-@pytest.mark.parametrize("case", ["plus", "inf", "hex", "short", "coff", "overflow", "junk", "negidx"])
+@pytest.mark.parametrize("case", ["plus", "inf", "hex", "short", "coff", "overflow", "junk"])
 def test_fast_off_reader_declines_what_it_cannot_reproduce(tmp_path, case):
     """Tokens whose treatment by operator>> is special (leading '+', inf, hex floats, range errors, junk, a file
     that ends early, COFF): the fast reader must decline, so that loadOFF behaves exactly like the token reader."""
@@ -187,7 +187,6 @@ def test_fast_off_reader_declines_what_it_cannot_reproduce(tmp_path, case):
     elif case == "coff": tag = "COFF"
     elif case == "overflow": v[4] = "1e40"
     elif case == "junk": v[3] = "1.5abc"
-    elif case == "negidx": faces[1] = "3 2 -1 0"
     p = tmp_path / f"{case}.off"
     _write_off(p, v, faces, tag=tag, nv=nv, nt=nt)
     same, fast, _, _ = host.off_compare(str(p))
@@ -205,6 +204,10 @@ def test_off_file_with_an_out_of_range_face_index_is_refused(tmp_path):
         bad.write_text(f"{tag}\n4 2 0\n" + "".join(f"{x} {y} 0{extra}\n" for x, y in ((0, 0), (1, 0), (1, 1), (0, 1))) + "3 0 1 2\n3 0 2 7\n")
         r = subprocess.run([rt_main, "--keys", "", "--off", str(bad)], capture_output=True, text=True, timeout=60)
         assert r.returncode != 0 and "refers to vertex 7 of 4" in r.stderr, (tag, r.returncode, r.stderr)
+    neg = tmp_path / "neg.off"   # operator>> reads "-1" into an unsigned as 4294967295
+    neg.write_text("OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 2 -1 0\n")
+    r = subprocess.run([rt_main, "--keys", "", "--off", str(neg)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "refers to vertex 4294967295 of 3" in r.stderr, (r.returncode, r.stderr)
 
 
 def test_triangle_count_limit():
