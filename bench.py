@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=3, help="spp of the bounded CPU-baseline sample of c1 / c2 (0 = skip the CPU baseline)")
     ap.add_argument("--flop-per-ray", type=float, default=0.0, help="override instead of counting on the CPU")
+    ap.add_argument("--native-gather", action="store_true", help="N > 1: exchange the tiles with the library's own RCCL calls (rt_gather_tiles_device)")
     args = ap.parse_args()
 
     import torch
@@ -141,8 +142,21 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     api.init(local_rank)
+    if world > 1 and args.native_gather:
+        box = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        api.comm_init(box[0], rank, world)
 
-    wl = workloads.make(args.config)                    # scene built by the product's host code
+    # scene built by the product's host code; like the reference, Scene::setup_cornell_box_meshes announces the mesh it loaded
+    # on stdout: sent to stderr here, stdout carries the JSON line only
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        wl = workloads.make(args.config)
+    finally:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     w, h, spp, tw, th = args.width or wl.w, args.height or wl.h, args.spp or wl.spp, args.tile, args.tile
     pass_spp = min(wl.pass_spp, spp)
     steps = args.steps or (2 if args.config == "c4" else 5)
@@ -160,7 +174,7 @@ def main():
         def render_fn(out, r, wd):  # progressive: the passes of one frame, sums staying in the tile buffer
             for s0 in range(0, spp, pass_spp):
                 one_pass(out, r, wd, s0, min(pass_spp, spp - s0), spp)
-    renderer = parallel_render.ShardedRenderer(w, h, tw, th, dev, render_fn)
+    renderer = parallel_render.ShardedRenderer(w, h, tw, th, dev, render_fn, native_gather=args.native_gather and world > 1)
     stream = torch.cuda.current_stream(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     image = None
@@ -269,7 +283,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {wl.what} {w}x{h} {spp}spp" + (f" in passes of {pass_spp}" if pass_spp != spp else "") +
                                    f" bounces10 light_samples16 counter-rng seed {args.seed}",
-                       "tile": f"{tw}x{th}", "parallelism": f"tiles t%{world} per GPU + RCCL gather to rank 0",
+                       "tile": f"{tw}x{th}", "parallelism": f"tiles t%{world} per GPU + RCCL gather to rank 0" + (" (rt_gather_tiles_device)" if args.native_gather and world > 1 else ""),
                        "triangles": int(wl.desc.n_triangles), "scene_upload_s": round(t_build, 3),
                        "rays_traced_per_step": int(traced_total / steps), "reference_rays_per_step": int(rays_total / steps),
                        "reference_mrays_per_s": round(rays_total / dt_max / 1e6, 2),

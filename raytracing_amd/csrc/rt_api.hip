@@ -767,7 +767,7 @@ struct SceneRes {
     DeviceScene dev{};
     int mode = 0;
     bool has_bounce = false; /* some sphere is a mirror or glass: only then do path trees differ in depth */
-    size_t n_tris = 0, n_bvh = 0, n_normals = 0; /* lengths of the device tables (their host copies are dropped) */
+    size_t n_tris = 0, n_bvh = 0, n_bvh4 = 0, n_normals = 0; /* lengths of the device tables (their host copies are dropped) */
     int bvh_depth = 0;
     rt_build_times times{};
     std::vector<void*> allocs;
@@ -952,6 +952,26 @@ int bvhs_on_device(SceneRes* r, const std::vector<uint32_t>& bvh_todo, const std
     return RT_OK;
 }
 
+/* Part 3 (both build paths): the four-wide trees the rays walk, made on the device from the binary node table. */
+int bvh4_on_device(SceneRes* r) {
+    if (!r->n_bvh) return RT_OK;
+    std::vector<int32_t> roots, roots4;
+    std::vector<size_t> owner;
+    for (size_t k = 0; k < r->host.meshes.size(); ++k)
+        if (r->host.meshes[k].bvh_root >= 0) { roots.push_back(r->host.meshes[k].bvh_root); owner.push_back(k); }
+    roots4.assign(roots.size(), -1);
+    DBvh4Node* nodes = nullptr;
+    uint32_t n4 = 0;
+    std::string err;
+    hipError_t e = rtd::collapse_to_bvh4(r->dev.bvh, (uint32_t)r->n_bvh, roots.data(), (uint32_t)roots.size(), g.stream, &nodes, &n4, roots4.data(), err);
+    if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_create: " + err);
+    r->allocs.push_back(nodes);
+    r->dev.bvh4 = nodes;
+    r->n_bvh4 = n4;
+    for (size_t k = 0; k < owner.size(); ++k) r->host.meshes[owner[k]].bvh4_root = roots4[k];
+    return RT_OK;
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 int make_render_params(uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w, uint32_t tile_h, uint32_t rank,
@@ -1127,6 +1147,7 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
     std::vector<float> bvh_pad;
     if (device_bvh && !r->host.meshes.empty() && (rc = meshes_on_device(*desc, r, bvh_todo, bvh_pad))) { release(r); return rc; }
     if (!bvh_todo.empty() && (rc = bvhs_on_device(r, bvh_todo, bvh_pad))) { release(r); return rc; }
+    if ((rc = bvh4_on_device(r))) { release(r); return rc; }
     if ((rc = upload(r, r->host.meshes, &d.meshes))) { release(r); return rc; }
     d.n_spheres = (uint32_t)r->host.spheres.size(); d.n_squares = (uint32_t)r->host.squares.size();
     d.n_meshes = (uint32_t)r->host.meshes.size(); d.n_lights = (uint32_t)r->host.lights.size();
@@ -1180,9 +1201,12 @@ int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times
         HIP_TRY(hipMemcpy(b.tri_orig.data(), r->dev.tri_orig, r->n_tris * 4, hipMemcpyDeviceToHost));
     }
     if (r->n_bvh) HIP_TRY(hipMemcpy(b.bvh.data(), r->dev.bvh, r->n_bvh * sizeof(DBvhNode), hipMemcpyDeviceToHost));
-    int depth = 0;
+    int depth = 0, stack4 = 0;
     std::string err;
     if (!rtb::verify_bvh(b, depth, err)) return fail(RT_E_LIMIT, err);
+    std::vector<DBvh4Node> wide(r->n_bvh4); /* and the four-wide trees the rays actually walk */
+    if (r->n_bvh4) HIP_TRY(hipMemcpy(wide.data(), r->dev.bvh4, r->n_bvh4 * sizeof(DBvh4Node), hipMemcpyDeviceToHost));
+    if (!rtb::verify_bvh4(b, wide, stack4, err)) return fail(RT_E_LIMIT, err);
     if (info) {
         std::memset(info, 0, sizeof(*info));
         int kd_depth = 0;
@@ -1192,7 +1216,7 @@ int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times
         info->bvh_nodes = (uint32_t)r->n_bvh; info->bvh_max_depth = (uint32_t)depth;
         info->kernel_variant = (uint32_t)r->mode;
         info->device_bytes = r->host.spheres.size() * sizeof(DSphere) + r->host.squares.size() * sizeof(DSquare) + b.meshes.size() * sizeof(DMesh) +
-                             r->n_tris * (sizeof(DTri) + 4) + r->n_bvh * sizeof(DBvhNode) + (size_t)r->n_normals * 4 +
+                             r->n_tris * (sizeof(DTri) + 4) + r->n_bvh * sizeof(DBvhNode) + r->n_bvh4 * sizeof(DBvh4Node) + (size_t)r->n_normals * 4 +
                              r->host.materials.size() * sizeof(DMaterial) + r->host.lights.size() * sizeof(DLight) +
                              r->host.kd.size() * sizeof(DKdNode) + r->host.refs.size() * sizeof(DRef);
     }

@@ -391,6 +391,62 @@ bool verify_bvh(const Built& b, int& max_depth, std::string& err) {
     return true;
 }
 
+bool verify_bvh4(const Built& b, const std::vector<DBvh4Node>& bvh4, int& max_stack, std::string& err) {
+    max_stack = 0;
+    std::vector<uint8_t> seen(b.tris.size(), 0);
+    struct Item { int32_t node; int depth, pending; float lo[3], hi[3]; };
+    for (size_t mi = 0; mi < b.meshes.size(); ++mi) {
+        const DMesh& m = b.meshes[mi];
+        if (m.bvh_root < 0) continue;
+        if (m.bvh4_root < 0) return fail(err, "bvh4: a mesh with a binary tree has no four-wide tree");
+        std::vector<Item> todo;
+        Item root{m.bvh4_root, 1, 0, {m.lo[0], m.lo[1], m.lo[2]}, {m.hi[0], m.hi[1], m.hi[2]}};
+        todo.push_back(root);
+        size_t leaves_tris = 0;
+        while (!todo.empty()) {
+            Item it = todo.back(); todo.pop_back();
+            if (it.node < 0 || (size_t)it.node >= bvh4.size()) return fail(err, "bvh4: node index out of range");
+            if (it.depth > kBvhMaxDepth / 2 + 1) return fail(err, "bvh4: path longer than half the binary depth limit");
+            const DBvh4Node& n = bvh4[(size_t)it.node];
+            const float* lo[4] = {n.half[0].lo0, n.half[0].lo1, n.half[1].lo0, n.half[1].lo1};
+            const float* hi[4] = {n.half[0].hi0, n.half[0].hi1, n.half[1].hi0, n.half[1].hi1};
+            const int32_t c[4] = {n.half[0].c0, n.half[0].c1, n.half[1].c0, n.half[1].c1};
+            const int32_t cnt[4] = {n.half[0].n0, n.half[0].n1, n.half[1].n0, n.half[1].n1};
+            int used = 0;
+            for (int k = 0; k < 4; ++k) used += (cnt[k] == 0 && c[k] < 0) ? 0 : 1;
+            if (used == 0) return fail(err, "bvh4: node without children");
+            /* the traversal leaves at most used - 1 entries on its stack per node of the path */
+            const int pending = it.pending + used - 1;
+            max_stack = std::max(max_stack, pending);
+            for (int k = 0; k < 4; ++k) {
+                if (cnt[k] == 0 && c[k] < 0) continue;
+                for (int a = 0; a < 3; ++a)
+                    if (lo[k][a] < it.lo[a] || hi[k][a] > it.hi[a]) return fail(err, "bvh4: child box sticks out of its parent");
+                if (cnt[k] == 0) {
+                    Item ch{c[k], it.depth + 1, pending, {lo[k][0], lo[k][1], lo[k][2]}, {hi[k][0], hi[k][1], hi[k][2]}};
+                    todo.push_back(ch);
+                    continue;
+                }
+                if (cnt[k] < 1 || cnt[k] > 4) return fail(err, "bvh4: leaf size outside 1..4");
+                for (int32_t t = c[k]; t < c[k] + cnt[k]; ++t) {
+                    if (t < (int32_t)m.first_tri || t >= (int32_t)(m.first_tri + m.n_tris)) return fail(err, "bvh4: leaf triangle outside the mesh");
+                    if (seen[(size_t)t]++) return fail(err, "bvh4: triangle in two leaves");
+                    ++leaves_tris;
+                    const DTri& tr = b.tris[(size_t)t];
+                    for (int a = 0; a < 3; ++a) {
+                        float v[3] = {tr.v0[a], tr.v0[a] + tr.e1[a], tr.v0[a] + tr.e2[a]};
+                        for (float x : v)
+                            if (x < lo[k][a] || x > hi[k][a]) return fail(err, "bvh4: triangle vertex outside its leaf box");
+                    }
+                }
+            }
+        }
+        if (leaves_tris != m.n_tris) return fail(err, "bvh4: a triangle is in no leaf");
+    }
+    if (max_stack > kBvhMaxDepth + kBvhMaxDepth / 2) return fail(err, "bvh4: a path needs more stack entries than the traversal has");
+    return true;
+}
+
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defer_meshes) {
     out = Built();
     if ((d.n_spheres && !d.spheres) || (d.n_squares && !d.squares) || (d.n_meshes && !d.meshes) ||
@@ -438,7 +494,7 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defe
         if ((uint64_t)m.first_vertex + m.n_vertices > d.n_vertices || (uint64_t)m.first_triangle + m.n_triangles > d.n_triangles)
             return fail(err, "rt_scene_create: mesh slice outside the vertex / triangle pools");
         DMesh o{};
-        o.mat = m.material; o.bvh_root = -1; o.n_tris = m.n_triangles;
+        o.mat = m.material; o.bvh_root = -1; o.bvh4_root = -1; o.pad1 = 0.f; o.n_tris = m.n_triangles;
         if (defer_meshes) { /* records, bounds and BVH are made on the device from the caller's arrays */
             o.first_tri = (uint32_t)deferred_tris;
             deferred_tris += m.n_triangles;

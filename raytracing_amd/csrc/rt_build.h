@@ -41,6 +41,9 @@ float mesh_bounds_from_box(const float lo[3], const float hi[3], uint32_t count,
  * 1..4 triangles, every child box contains the (padded) boxes below it and its triangles' vertices, and no
  * root-to-leaf path has more than kBvhMaxDepth inner nodes.  max_depth returns the longest path found. */
 bool verify_bvh(const Built& b, int& max_depth, std::string& err);
+/* The same walk over the four-wide trees the rays traverse (b.meshes[].bvh4_root into bvh4): every triangle of a BVH mesh in
+ * exactly one leaf, boxes nested and enclosing their triangles; max_stack = the most entries a traversal can have pending. */
+bool verify_bvh4(const Built& b, const std::vector<DBvh4Node>& bvh4, int& max_stack, std::string& err);
 bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err);
 
 }  // namespace rtb

@@ -39,5 +39,12 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
                           const float hi[3], float pad, int32_t node_base, int max_levels, hipStream_t stream,
                           DeviceBvh& out, std::string& err);
 
+/* The four-wide form of a table of binary trees (DBvh4Node, rt_types.h): every node at an even depth of its tree is
+ * kept and takes over the children of its inner children.  d_bvh2[0, n2): the binary nodes of all meshes (child
+ * indices into the same table); roots[0, n_roots): the root nodes, roots4 gets their positions in the new table.
+ * The new table comes back in a fresh device array (hipFree by the caller).  Blocks until done. */
+hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, uint32_t n_roots, hipStream_t stream,
+                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err);
+
 }  // namespace rtd
 #endif

@@ -242,6 +242,62 @@ __global__ void __launch_bounds__(256) k_make_tris(const float* positions, const
     }
 }
 
+/* ---- binary tree -> four-wide tree ------------------------------------------------------------------------ */
+__device__ inline bool child_inner(int32_t c, int32_t n) { return n == 0 && c >= 0; }
+__device__ inline bool child_empty(int32_t c, int32_t n) { return n == 0 && c < 0; }
+
+__global__ void __launch_bounds__(256) k_parents(const DBvhNode* nodes, uint32_t n2, int32_t* parent) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n2) return;
+    const DBvhNode n = nodes[i];
+    if (child_inner(n.c0, n.n0)) parent[n.c0] = (int32_t)i;
+    if (child_inner(n.c1, n.n1)) parent[n.c1] = (int32_t)i;
+}
+
+/* keep[i] = 1 for the nodes at an even depth of their tree (the roots have no parent: depth 0) */
+__global__ void __launch_bounds__(256) k_even_depth(const int32_t* parent, uint32_t n2, uint32_t* keep) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n2) return;
+    uint32_t depth = 0;
+    for (int32_t p = parent[i]; p >= 0 && depth < 64u; p = parent[p]) ++depth; /* trees are at most 32 deep */
+    keep[i] = (depth & 1u) ? 0u : 1u;
+}
+
+__device__ inline void put_child(DBvh4Node& o, int slot, const float* lo, const float* hi, int32_t c, int32_t n) {
+    DBvhNode& h = o.half[slot >> 1];
+    float* dlo = (slot & 1) ? h.lo1 : h.lo0;
+    float* dhi = (slot & 1) ? h.hi1 : h.hi0;
+    for (int a = 0; a < 3; ++a) { dlo[a] = lo[a]; dhi[a] = hi[a]; }
+    if (slot & 1) { h.c1 = c; h.n1 = n; } else { h.c0 = c; h.n0 = n; }
+}
+
+__global__ void __launch_bounds__(256) k_collapse(const DBvhNode* nodes, uint32_t n2, const uint32_t* keep, const uint32_t* rank, DBvh4Node* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n2 || !keep[i]) return;
+    const DBvhNode n = nodes[i];
+    DBvh4Node o;
+    const float none_lo[3] = {INFINITY, INFINITY, INFINITY}, none_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int s = 0; s < 4; ++s) put_child(o, s, none_lo, none_hi, -1, 0);
+    int slot = 0;
+    const float* lo[2] = {n.lo0, n.lo1};
+    const float* hi[2] = {n.hi0, n.hi1};
+    const int32_t c[2] = {n.c0, n.c1}, cnt[2] = {n.n0, n.n1};
+    for (int k = 0; k < 2; ++k) {
+        if (child_empty(c[k], cnt[k])) continue;
+        if (!child_inner(c[k], cnt[k])) { put_child(o, slot++, lo[k], hi[k], c[k], cnt[k]); continue; } /* a leaf stays where it is */
+        const DBvhNode m = nodes[c[k]]; /* an inner child (odd depth) hands over its own children (even depth, or leaves) */
+        const float* mlo[2] = {m.lo0, m.lo1};
+        const float* mhi[2] = {m.hi0, m.hi1};
+        const int32_t mc[2] = {m.c0, m.c1}, mn[2] = {m.n0, m.n1};
+        for (int j = 0; j < 2; ++j) {
+            if (child_empty(mc[j], mn[j])) continue;
+            const int32_t code = child_inner(mc[j], mn[j]) ? (int32_t)rank[mc[j]] : mc[j];
+            put_child(o, slot++, mlo[j], mhi[j], code, mn[j]);
+        }
+    }
+    out[rank[i]] = o;
+}
+
 struct Temps {
     std::vector<void*> ptrs;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -382,6 +438,43 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
     out.max_depth = (int)level_end.size();
     (void)hipEventElapsedTime(&out.sort_ms, tmp.ev[0], tmp.ev[1]);
     (void)hipEventElapsedTime(&out.tree_ms, tmp.ev[1], tmp.ev[2]);
+    return hipSuccess;
+}
+
+hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, uint32_t n_roots, hipStream_t stream,
+                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err) {
+    *d_bvh4 = nullptr; *n4 = 0;
+    if (n2 == 0) return hipSuccess;
+    Temps tmp;
+    int32_t* parent;
+    uint32_t *keep, *rank;
+    void* scan_tmp = nullptr;
+    size_t scan_bytes = 0;
+    BVH_TRY(tmp.get(&parent, n2));
+    BVH_TRY(tmp.get(&keep, (size_t)n2 + 1));
+    BVH_TRY(tmp.get(&rank, (size_t)n2 + 1));
+    BVH_TRY(hipMemsetAsync(parent, 0xff, (size_t)n2 * 4, stream));
+    BVH_TRY(hipMemsetAsync(keep, 0, ((size_t)n2 + 1) * 4, stream));
+    hipLaunchKernelGGL(k_parents, dim3(blocks(n2)), dim3(256), 0, stream, d_bvh2, n2, parent);
+    hipLaunchKernelGGL(k_even_depth, dim3(blocks(n2)), dim3(256), 0, stream, (const int32_t*)parent, n2, keep);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, keep, rank, 0u, (size_t)n2 + 1, rocprim::plus<uint32_t>(), stream));
+    BVH_TRY(tmp.get((char**)&scan_tmp, scan_bytes));
+    BVH_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, keep, rank, 0u, (size_t)n2 + 1, rocprim::plus<uint32_t>(), stream));
+    uint32_t total = 0;
+    BVH_TRY(hipMemcpyAsync(&total, rank + n2, 4, hipMemcpyDeviceToHost, stream));
+    for (uint32_t k = 0; k < n_roots; ++k) {
+        if (roots[k] < 0 || (uint32_t)roots[k] >= n2) { err = "four-wide BVH: root outside the node table"; return hipErrorInvalidValue; }
+        BVH_TRY(hipMemcpyAsync(&roots4[k], rank + roots[k], 4, hipMemcpyDeviceToHost, stream));
+    }
+    BVH_TRY(hipStreamSynchronize(stream));
+    DBvh4Node* out = nullptr;
+    BVH_TRY(hipMalloc((void**)&out, (size_t)(total ? total : 1) * sizeof(DBvh4Node)));
+    hipLaunchKernelGGL(k_collapse, dim3(blocks(n2)), dim3(256), 0, stream, d_bvh2, n2, (const uint32_t*)keep, (const uint32_t*)rank, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { (void)hipFree(out); err = std::string("four-wide BVH: ") + hipGetErrorString(e); return e; }
+    *d_bvh4 = out; *n4 = total;
     return hipSuccess;
 }
 

@@ -284,7 +284,10 @@ RT_DEV bool bvh_reaches(const DMesh& m, f3 o, f3 d, float limit) {
     float tn;
     return slab(m.lo, m.hi, o, bvh_inv_dir(d), limit, tn);
 }
-/* The traversal proper; the caller has checked bvh_reaches. */
+/* The traversal proper; the caller has checked bvh_reaches.  It walks the four-wide tree (DBvh4Node): one 128-byte fetch
+ * decides among four subtrees, the hit ones are visited nearest first.  Stack: RT_STACK_LDS entries in LDS, and what a
+ * path could need beyond them (three pushes per level, RT_STACK_LDS / 2 levels at most) in a small per-lane array. */
+#define RT_STACK_OVER (RT_STACK_LDS / 2)
 template <bool ANY>
 RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
                      float& best_u, float& best_v) {
@@ -293,30 +296,48 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
     int sp = 0;
     bool found = false;
     uint32_t best_orig = 0xffffffffu;
-    int cur = m.bvh_root;
-    auto push = [&](int e) { cnt.stack[(sp++ & (RT_STACK_LDS - 1)) * cnt.stack_stride] = (uint32_t)e; }; /* never wraps: depth <= RT_STACK_LDS */
-    auto pop = [&]() -> int { return (int)cnt.stack[(--sp & (RT_STACK_LDS - 1)) * cnt.stack_stride]; };
+    int over[RT_STACK_OVER];
+    auto push = [&](int e) {
+        if (sp < RT_STACK_LDS) cnt.stack[sp * cnt.stack_stride] = (uint32_t)e; else over[(sp - RT_STACK_LDS) & (RT_STACK_OVER - 1)] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> int {
+        --sp;
+        return sp < RT_STACK_LDS ? (int)cnt.stack[sp * cnt.stack_stride] : over[(sp - RT_STACK_LDS) & (RT_STACK_OVER - 1)];
+    };
+    int cur = m.bvh4_root;
     bool done = false;
-    auto visit = [&](const DBvhNode& n) { /* both child boxes of one inner node: where to go next */
-        ++cnt.bvh_nodes;
-        float t0, t1;
-        bool h0 = slab(n.lo0, n.hi0, o, id, best_t, t0) && !(n.n0 == 0 && n.c0 < 0);
-        bool h1 = slab(n.lo1, n.hi1, o, id, best_t, t1) && !(n.n1 == 0 && n.c1 < 0);
-        int e0 = n.n0 > 0 ? ~(n.c0 * 8 + n.n0) : n.c0;
-        int e1 = n.n1 > 0 ? ~(n.c1 * 8 + n.n1) : n.c1;
-        if (h0 && h1) {
-            bool first0 = t0 <= t1;
-            push(first0 ? e1 : e0);
-            cur = first0 ? e0 : e1;
-        } else if (h0) cur = e0;
-        else if (h1) cur = e1;
+    auto visit = [&](const DBvh4Node& n) { /* the four child boxes of one node: where to go next, what to keep for later */
+        cnt.bvh_nodes += 2; /* counted in 64-byte units */
+        float t0, t1, t2, t3;
+        const DBvhNode& a = n.half[0];
+        const DBvhNode& b = n.half[1];
+        const bool h0 = slab(a.lo0, a.hi0, o, id, best_t, t0) && !(a.n0 == 0 && a.c0 < 0);
+        const bool h1 = slab(a.lo1, a.hi1, o, id, best_t, t1) && !(a.n1 == 0 && a.c1 < 0);
+        const bool h2 = slab(b.lo0, b.hi0, o, id, best_t, t2) && !(b.n0 == 0 && b.c0 < 0);
+        const bool h3 = slab(b.lo1, b.hi1, o, id, best_t, t3) && !(b.n1 == 0 && b.c1 < 0);
+        int e0 = a.n0 > 0 ? ~(a.c0 * 8 + a.n0) : a.c0, e1 = a.n1 > 0 ? ~(a.c1 * 8 + a.n1) : a.c1;
+        int e2 = b.n0 > 0 ? ~(b.c0 * 8 + b.n0) : b.c0, e3 = b.n1 > 0 ? ~(b.c1 * 8 + b.n1) : b.c1;
+        /* entry distances, +inf for a child that is not visited; sorted ascending by a five-comparator network */
+        float k0 = h0 ? t0 : RT_INF, k1 = h1 ? t1 : RT_INF, k2 = h2 ? t2 : RT_INF, k3 = h3 ? t3 : RT_INF;
+        auto order = [](float& ka, int& ea, float& kb, int& eb) {
+            const bool sw = kb < ka;
+            const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt;
+            const int et = sw ? eb : ea; eb = sw ? ea : eb; ea = et;
+        };
+        order(k0, e0, k1, e1); order(k2, e2, k3, e3); order(k0, e0, k2, e2); order(k1, e1, k3, e3); order(k1, e1, k2, e2);
+        const int hits = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+        if (hits > 3) push(e3);
+        if (hits > 2) push(e2);
+        if (hits > 1) push(e1);
+        if (hits > 0) cur = e0;
         else if (sp > 0) cur = pop();
         else done = true;
     };
     /* the root is the same node for every lane: its address is wave-uniform, so this fetch is a scalar load */
-    visit(ldc(&sc.bvh[m.bvh_root]));
+    visit(ldc(&sc.bvh4[m.bvh4_root]));
     for (;;) {
-        while (!done && cur >= 0) visit(ldc(&sc.bvh[cur])); /* inner nodes */
+        while (!done && cur >= 0) visit(ldc(&sc.bvh4[cur])); /* inner nodes */
         if (done) break;
         { /* leaf */
             int code = ~cur;

@@ -62,7 +62,7 @@ struct DMesh {  /* 64 B */
     int32_t bvh_root;  /* index into DeviceScene::bvh, -1 = brute force over the triangle range */
     float bs_c[3];     /* with a BVH: a sphere around the padded root box; a ray whose line misses it, or */
     float bs_r2;       /* that leaves it behind, skips the traversal (squared radius, rounded up)         */
-    float lo[3]; float pad0; /* the padded root box itself */
+    float lo[3]; int32_t bvh4_root; /* the padded root box itself; bvh4_root: index into DeviceScene::bvh4, the tree the rays walk */
     float hi[3]; float pad1;
 };
 
@@ -76,6 +76,14 @@ struct DBvhNode {
     float hi0[3]; int32_t n0;
     float lo1[3]; int32_t c1;
     float hi1[3]; int32_t n1;
+};
+
+/* The tree the rays walk: four children per node (128 B, eight dwordx4 loads), made from the binary tree by giving every
+ * node at an even depth the children of its inner children.  One fetch then decides among four subtrees, and a path
+ * from the root has half as many dependent fetches.  Two binary records back to back: children 0, 1 in half[0],
+ * children 2, 3 in half[1]; same child encoding; an unused slot is an empty child (c < 0, n == 0) with an empty box. */
+struct DBvh4Node {
+    DBvhNode half[2];
 };
 
 /* Object-level kd-tree node, R/src/KDTree.h:12-29, children by index, leaf refs by range. */
@@ -92,7 +100,8 @@ struct DeviceScene {
     const DMesh* meshes;
     const DTri* tris;           /* per mesh: original order (brute force) or BVH leaf order */
     const uint32_t* tri_orig;   /* mesh-local original index of tris[i]: tIndex and the tie-break */
-    const DBvhNode* bvh;
+    const DBvhNode* bvh;        /* binary trees as built (kept for verification) */
+    const DBvh4Node* bvh4;      /* their four-wide form, what bvh_walk traverses */
     const float* normals;  /* xyz per vertex */
     const DMaterial* materials;
     const DLight* lights;

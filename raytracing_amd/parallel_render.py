@@ -57,7 +57,10 @@ class ShardedRenderer:
     one frame runs while the next one renders.  flush() finishes the frame still in flight.  With
     pipelined=False every step() finishes its own frame."""
 
-    def __init__(self, w, h, tile_w, tile_h, device, render_tiles_fn, pipelined=True):
+    def __init__(self, w, h, tile_w, tile_h, device, render_tiles_fn, pipelined=True, native_gather=False):
+        """native_gather: the exchange is rt_gather_tiles_device (RCCL point-to-point calls made by the library, enqueued on
+        the current stream; needs api.comm_init) instead of torch.distributed.gather."""
+        self.native_gather = native_gather
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.layout = TileLayout(w, h, tile_w, tile_h, self.world)
@@ -80,7 +83,7 @@ class ShardedRenderer:
                     self.gathered[k] = list(self.gathered_flat[k].chunk(self.world))
             self.image = torch.zeros(h * w * 3, dtype=torch.float32, device=device)
             self.perm = torch.from_numpy(self.layout.scatter_index()).to(device)
-        if self.world > 1:
+        if self.world > 1 and not self.native_gather:
             # set-up, not a frame: the first gather opens the point-to-point channels to rank 0 (tens of ms on RCCL)
             probe = torch.zeros(1, dtype=torch.float32, device=device)
             dist.gather(probe, [torch.zeros_like(probe) for _ in range(self.world)] if self.rank == 0 else None, dst=0)
@@ -104,7 +107,10 @@ class ShardedRenderer:
         self.frame += 1
         self.render_tiles_fn(self.mine[k], self.rank, self.world)
         work = None
-        if self.world > 1:
+        if self.world > 1 and self.native_gather:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            api.gather_tiles_device(self.mine[k].data_ptr(), self.mine[k].numel(), self.gathered_flat[k].data_ptr() if self.rank == 0 else 0, 0, stream)
+        elif self.world > 1:
             work = dist.gather(self.mine[k], self.gathered[k], dst=0, async_op=True)
         if not self.pipelined:
             return self._finish((work, k))
