@@ -879,6 +879,11 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                 const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
                 const Rng at_first = rng; /* the stream position of light sample 0 */
                 uint32_t dark = 0, near = 0; /* bit i: light sample i is occluded / still has to be walked through a BVH */
+                /* With a BVH in the scene a batch whose rays are all decided (no lane of the wave has one that comes near a
+                 * mesh: the usual case away from the meshes) adds its light terms right away, like the variants without a
+                 * BVH.  From the first batch that leaves a ray open the terms wait -- the sum runs in sample order -- and
+                 * are added after the walks, their light directions rebuilt from the random stream. */
+                uint32_t first_open = 16; /* wave-uniform: the first sample whose light term is still to be added */
                 for (int i0 = 0; i0 < 16; i0 += RT_SB) {
                     f3 L[RT_SB], Ld[RT_SB];
                     float dist[RT_SB];
@@ -895,21 +900,25 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
                     shadow_batch<M, RT_SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt);
-                    if (!(M & RT_M_BVH)) { /* every ray is decided: add the light terms in sample order right away */
-#pragma unroll
-                        for (int j = 0; j < RT_SB; ++j)
-                            if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
-                    } else {
+                    bool now = true; /* every ray of the batch is decided: add the light terms in sample order right away */
+                    if (M & RT_M_BVH) {
+                        if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;
+                        now = first_open == 16;
 #pragma unroll
                         for (int j = 0; j < RT_SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
                         near |= near4 << i0;
                     }
+                    if (now) {
+#pragma unroll
+                        for (int j = 0; j < RT_SB; ++j)
+                            if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
+                    }
                 }
-                if (M & RT_M_BVH) {
-                    /* the undecided rays of all 16 samples in one go, then the sum in sample order; a light direction
+                if ((M & RT_M_BVH) && first_open < 16) {
+                    /* the undecided rays of all samples in one go, then the rest of the sum in sample order; a light direction
                      * is cheaper to rebuild from the random stream than to keep over the traversals */
                     if (__ballot(near != 0)) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
-                    for (uint32_t i = 0; i < 16; ++i) {
+                    for (uint32_t i = first_open; i < 16; ++i) {
                         if ((dark >> i) & 1u) continue;
                         float len;
                         light_term(sum, lt, m, N, V, norm3_len(light_sample(at_first, i, p0, p1, p2) - P, len));
