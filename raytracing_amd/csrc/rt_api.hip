@@ -214,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_tile_place(uint32_t* __restrict__ ws, 
  * A pixel on the deep list has path trees of hundreds of nodes per sample (glass seen through glass).  Walked depth
  * first by one lane per sample they are chains of hundreds of dependent closest-hit and shadow queries, and the wave
  * that holds them is still running when the rest of the launch is done.  A worker wave instead expands the trees of up
- * to RT_TREE_BATCH samples of such a pixel breadth first -- the recursion of R/src/Scene.h:596-713 has depth <= 11, so
+ * to RT_TREE_BATCH samples of such pixels breadth first -- the recursion of R/src/Scene.h:596-713 has depth <= 11, so
  * 11 rounds of closest-hit queries, one lane per node, find every node -- and then shades all nodes that need it side
  * by side.  What the recursion's order decides is kept:
  *   random numbers  a node that was hit draws 32 numbers per quad light (R/src/Scene.h:369-370), nodes in depth-first
@@ -225,11 +225,17 @@ __global__ __launch_bounds__(1024) void k_tile_place(uint32_t* __restrict__ ws, 
  * gets the same floats whichever way it is rendered.  Children are appended to the next level with one ballot per
  * chunk of 64 nodes.  Node fields live in this worker's slice of dl.tree (field f of node i at
  * [f * RT_TREE_NODES + i]); a batch whose trees do not fit is cut in halves (one sample's tree has at most 2047 nodes).
- * Workers take items (a listed pixel and a group of RT_TREE_BATCH of the pass's samples) from a counter until none is
+ * Workers take items (RT_TREE_BATCH consecutive samples of the pass's deep samples, listed pixel by listed pixel: the
+ * samples of one item belong to one pixel or to pixels the probe listed next to each other) from a counter until none is
  * left; they are the first workgroups of the grid, so the long items start first. */
 #define RT_TREE_NODES 2048
 #define RT_TREE_WORDS 14
-#define RT_TREE_BATCH 16
+#ifndef RT_TREE_BATCH
+#define RT_TREE_BATCH 32
+#endif
+#ifndef RT_TREE_WORKERS
+#define RT_TREE_WORKERS 4096
+#endif
 enum { TF_A0 = 0, TF_META = 6, TF_OBJ = 7, TF_F = 8, TF_C1 = 9, TF_C2 = 10, TF_SIZE = 11, TF_PRE = 12, TF_LIST = 13 };
 /* fields 0..5: the node's ray (origin, direction) until it is traced, then hit position and normal, then (0..2) its colour.
  * meta = kind | hit type << 4 | sample of the batch << 8; kind 0 miss, 1 hit without children, 2 mirror, 3 glass with
@@ -241,16 +247,27 @@ RT_DEV void tree_sync() { /* this wave's stores to the tree are visible to its l
 }
 template <int M>
 RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, const RenderParams& rp, uint32_t* __restrict__ mem, uint32_t* s_lv,
-                       uint32_t x, uint32_t y, uint32_t s_first, uint32_t n_samples, uint32_t draws_per_node, float* __restrict__ colors, Cnt& cnt) {
+                       const DeepList& dl, uint32_t f_first, uint32_t n_samples, uint32_t draws_per_node, Cnt& cnt) {
     const uint32_t lane = threadIdx.x & 63;
+    /* sample f of the pass's deep samples = sample f % spp of listed pixel f / spp; pixel index and sample number of it */
+    auto sample_of = [&](uint32_t f, uint32_t& pixel, uint32_t& s) {
+        const uint32_t pix = dl.pixels[f / rp.spp], px_per_tile = rp.tile_w * rp.tile_h;
+        const uint32_t tile = rp.rank + (pix / px_per_tile) * rp.world, in_tile = pix % px_per_tile;
+        const uint32_t x = rt_tile_column(tile, rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
+        const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
+        pixel = x + y * rp.w;
+        s = rp.sample0 + f % rp.spp;
+    };
     auto fld = [&](int f, uint32_t i) -> uint32_t& { return mem[(uint32_t)f * RT_TREE_NODES + i]; };
     auto put3 = [&](int f, uint32_t i, f3 v) { fld(f, i) = __float_as_uint(v.x); fld(f + 1, i) = __float_as_uint(v.y); fld(f + 2, i) = __float_as_uint(v.z); };
     auto get3 = [&](int f, uint32_t i) { return mk3(__uint_as_float(fld(f, i)), __uint_as_float(fld(f + 1, i)), __uint_as_float(fld(f + 2, i))); };
     /* roots: R/main.cpp:186-190 */
     if (lane < n_samples) {
-        Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, rp.sample0 + s_first + lane); rng.k = 0;
-        float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
-        float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
+        uint32_t pixel, smp;
+        sample_of(f_first + lane, pixel, smp);
+        Rng rng; rng.key = rt_rng_key(rp.seed, pixel, smp); rng.k = 0;
+        float u = ((float)(int)(pixel % rp.w) + rng.unit()) / (float)(int)rp.w;
+        float v = ((float)(int)(pixel / rp.w) + rng.unit()) / (float)(int)rp.h;
         f3 o, d;
         primary_ray(*cam, u, v, o, d);
         put3(TF_A0, lane, o);
@@ -364,8 +381,10 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
             FullHit h;
             h.hit = true; h.type = (int)((meta >> 4) & 15u); h.obj = (int)fld(TF_OBJ, i); h.tri = -1; h.t = 0.f;
             h.p = get3(TF_A0, i); h.n = get3(TF_A0 + 3, i);
+            uint32_t pixel, smp;
+            sample_of(f_first + (meta >> 8), pixel, smp);
             Rng rng;
-            rng.key = rt_rng_key(rp.seed, x + y * rp.w, rp.sample0 + s_first + (meta >> 8));
+            rng.key = rt_rng_key(rp.seed, pixel, smp);
             rng.k = 2u + draws_per_node * fld(TF_PRE, i);
             put3(TF_A0, i, shade<M>(sc, h, rng, cnt));
         }
@@ -395,7 +414,7 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
     }
     if (lane < n_samples) {
         const f3 col = get3(TF_A0, lane);
-        float* dst = colors + 3ull * (s_first + lane);
+        float* dst = dl.colors + 3ull * (f_first + lane);
         dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     }
     tree_sync(); /* the next batch overwrites the tree */
@@ -410,29 +429,26 @@ RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ c
     pass.spp = spp; pass.sample0 = sample0;
     uint32_t draws = 0;
     for (uint32_t li = 0; li < sc.n_lights; ++li) draws += ldc(&sc.lights[li].type) == RT_LIGHT_QUAD ? 32u : 0u;
-    const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
     const uint32_t n_deep = min(dl.head[0], dl.cap);
-    const uint32_t groups = (spp + RT_TREE_BATCH - 1) / RT_TREE_BATCH;
-    const uint64_t n_items = (uint64_t)n_deep * groups;
+    const uint64_t n_samples = (uint64_t)n_deep * spp; /* < 2^32: the list's colour table holds them */
+    /* full chunks make a worker's lanes count, small items let the workers end together: the large batch only when
+     * every worker gets several items of it (measured: 10 M-triangle share, 2.3 items of 16 per worker: 25.3 ms with
+     * 16, 26.1 ms with 32; many-spheres kd frame, 64 spp: 41.7 ms with 16, 38.8 ms with 32) */
+    const uint32_t per_item = n_samples >= 2ull * RT_TREE_BATCH * dl.n_workers ? RT_TREE_BATCH : RT_TREE_BATCH / 2;
+    const uint64_t n_items = (n_samples + per_item - 1) / per_item;
     uint32_t samples = 0;
     for (;;) { /* ends for every worker: the counter only grows and n_items is fixed */
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(&dl.head[1], 1u);
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= n_items) break;
-        const uint32_t entry = item / groups, grp = item % groups;
-        const uint32_t pix = dl.pixels[entry];
-        const uint32_t local_tile = pix / px_per_tile, in_tile = pix % px_per_tile;
-        const uint32_t tile = rp.rank + local_tile * rp.world;
-        const uint32_t x = rt_tile_column(tile, rp.tiles_x) * rp.tile_w + in_tile % rp.tile_w;
-        const uint32_t y = (tile / rp.tiles_x) * rp.tile_h + in_tile / rp.tile_w;
-        const uint32_t s_end = min(spp, (grp + 1) * RT_TREE_BATCH);
-        uint32_t s0 = grp * RT_TREE_BATCH, batch = RT_TREE_BATCH;
-        while (s0 < s_end) {
-            const uint32_t n = min(batch, s_end - s0);
+        const uint32_t f_end = (uint32_t)min(n_samples, ((uint64_t)item + 1) * per_item);
+        uint32_t f0 = item * per_item, batch = per_item;
+        while (f0 < f_end) {
+            const uint32_t n = min(batch, f_end - f0);
             const Cnt before = cnt; /* a batch that does not fit is traced again in halves: its counts are dropped */
-            if (tree_batch<M>(sc, cam, pass, mem, s_lv, x, y, s0, n, draws, dl.colors + 3ull * (uint64_t)entry * spp, cnt)) {
-                s0 += n;
+            if (tree_batch<M>(sc, cam, pass, mem, s_lv, dl, f0, n, draws, cnt)) {
+                f0 += n;
                 if (lane == 0) samples += n;
             } else {
                 cnt = before;
@@ -471,7 +487,17 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
     if (blockIdx.x < n_workers) { /* the first workgroups of the launch expand the path trees of the deep list (n_workers > 0 only with RT_RENDER_WAVES == 1) */
         __shared__ uint32_t s_lv[16];
         Cnt wc = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES);
+#ifdef RT_WAVE_TIMES
+        const unsigned long long w_start = wall_clock64();
+#endif
         const uint32_t done = tree_worker<M>(sc, cam, rp, dl, blockIdx.x, pass_spp, pass_sample0, s_lv, wc);
+#ifdef RT_WAVE_TIMES
+        if (lane == 0 && rt_dbg_times) { /* worker b: after the records of the pixel waves; "pixel" = samples it traced */
+            const unsigned long long at = 3ull * ((unsigned long long)(gridDim.x - n_workers) * RT_RENDER_WAVES + blockIdx.x);
+            rt_dbg_times[at] = w_start; rt_dbg_times[at + 1] = wall_clock64();
+            rt_dbg_times[at + 2] = (0xfffffull << 44) | ((unsigned long long)min(done, 0xfffffu) << 24);
+        }
+#endif
         flush_counters<M>(counters, wc, done);
         return;
     }
@@ -1506,8 +1532,9 @@ static int render_pass(bool static_mem, rt_scene_t scene, const rt_camera* cam, 
                 const size_t off_pixels = off_head + 16, off_flags = off_pixels + (size_t)cap * 4;
                 const size_t off_colors = (off_flags + (want_wide ? (size_t)npx : 0) + 15) & ~(size_t)15;
                 const size_t colors_bytes = (size_t)cap * spp * 12;
-                /* worker waves: at most half of what the chip holds at 4 waves per SIMD, and no more than there can be items */
-                const uint32_t workers = (uint32_t)std::min<uint64_t>(2048, cap * ((spp + RT_TREE_BATCH - 1) / RT_TREE_BATCH));
+                /* worker waves: at most what the chip holds at 4 waves per SIMD (the deep samples are most of the work of a launch
+                 * that uses them; a worker without an item ends at once), and no more than there can be items */
+                const uint32_t workers = (uint32_t)std::min<uint64_t>(RT_TREE_WORKERS, (cap * spp + RT_TREE_BATCH / 2 - 1) / (RT_TREE_BATCH / 2));
                 const size_t off_tree = (off_colors + colors_bytes + 255) & ~(size_t)255;
                 const size_t bytes = off_tree + (size_t)workers * RT_TREE_NODES * RT_TREE_WORDS * 4;
                 if (g.order_used[slot] && g.order_stream[slot] != hip_stream) HIP_TRY(hipStreamWaitEvent(st, g.order_done[slot], 0));

@@ -52,7 +52,7 @@ if a.wave_times:
     L = api.lib()
     L.rt_debug_wave_times.argtypes = [C.c_void_p]
     per_wave = max(1, 64 // pass_spp) if pass_spp <= 32 else 1
-    n_waves = lay.per_rank * ((tw * th + per_wave - 1) // per_wave)
+    n_waves = lay.per_rank * ((tw * th + per_wave - 1) // per_wave) + 4096   # + the worker waves, recorded behind the pixel waves
     buf = torch.zeros(n_waves * 3, dtype=torch.int64, device=dev)
     assert L.rt_debug_wave_times(buf.data_ptr()) == 0
     for rank in ranks:
@@ -63,6 +63,12 @@ if a.wave_times:
         t = buf.cpu().numpy().reshape(-1, 3)
         t = t[t[:, 1] > 0]
         t0 = t[:, 0].min()
+        wk = t[((t[:, 2] >> 44) & 0xfffff) == 0xfffff]
+        if len(wk):
+            busy = wk[((wk[:, 2] >> 24) & 0xfffff) > 0]
+            print(f"rank {rank}: {len(wk)} worker waves, {len(busy)} traced samples ({int(((busy[:, 2] >> 24) & 0xfffff).sum())} in all); they end at "
+                  f"{[round(float(x)) for x in np.percentile((busy[:, 1] - t0) / 100.0, (50, 90, 100))] if len(busy) else []} us (50 / 90 / 100 %)")
+        t = t[((t[:, 2] >> 44) & 0xfffff) != 0xfffff]
         st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0   # us at 100 MHz
         dur = en - st
         print(f"rank {rank}: {len(t)} waves, launch span {en.max():.0f} us, sum of wave times / 4096 slots {dur.sum() / 4096:.0f} us, "
