@@ -418,8 +418,21 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
         dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     }
     tree_sync(); /* the next batch overwrites the tree */
+#ifdef RT_WAVE_TIMES
+    if (lane == 0) { s_lv[14] = n_nodes; s_lv[15] = n_list; }
+#endif
     return true;
 }
+#ifdef RT_WAVE_TIMES /* debug build only: start / end clock of every wave of k_render */
+__device__ unsigned long long* rt_dbg_times;
+__device__ unsigned long long* rt_dbg_items; /* behind the wave records: one record per worker batch */
+extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_times), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : -1;
+}
+extern "C" int rt_debug_worker_items(unsigned long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_items), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int M>
 RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ cam, const RenderParams& rp, const DeepList& dl, uint32_t worker,
                             uint32_t spp, uint32_t sample0, uint32_t* s_lv, Cnt& cnt) {
@@ -447,7 +460,17 @@ RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ c
         while (f0 < f_end) {
             const uint32_t n = min(batch, f_end - f0);
             const Cnt before = cnt; /* a batch that does not fit is traced again in halves: its counts are dropped */
+#ifdef RT_WAVE_TIMES
+            const unsigned long long b_start = wall_clock64();
+#endif
             if (tree_batch<M>(sc, cam, pass, mem, s_lv, dl, f0, n, draws, cnt)) {
+#ifdef RT_WAVE_TIMES
+                if (lane == 0 && rt_dbg_items) { /* one record per batch: start, end, nodes | shaded << 16 | samples << 32 | worker << 40 */
+                    unsigned long long* rec = rt_dbg_items + 3ull * (f0 / (RT_TREE_BATCH / 2));
+                    rec[0] = b_start; rec[1] = wall_clock64();
+                    rec[2] = (unsigned long long)s_lv[14] | ((unsigned long long)s_lv[15] << 16) | ((unsigned long long)n << 32) | ((unsigned long long)worker << 40);
+                }
+#endif
                 f0 += n;
                 if (lane == 0) samples += n;
             } else {
@@ -463,12 +486,6 @@ RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ c
 extern "C" int rt_debug_shade_hist(unsigned long long* out65, int reset) {
     if (reset) { unsigned long long z[65] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_hist), z, sizeof(z)) == hipSuccess ? 0 : -1; }
     return hipMemcpyFromSymbol(out65, HIP_SYMBOL(rt_dbg_hist), 65 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif
-#ifdef RT_WAVE_TIMES /* debug build only: start / end clock of every wave of k_render */
-__device__ unsigned long long* rt_dbg_times;
-extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_times), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : -1;
 }
 #endif
 /* One pass of the render: samples [sample0, sample0 + spp) of every pixel of this rank's tiles.

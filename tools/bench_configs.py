@@ -55,9 +55,13 @@ if a.wave_times:
     n_waves = lay.per_rank * ((tw * th + per_wave - 1) // per_wave) + 4096   # + the worker waves, recorded behind the pixel waves
     buf = torch.zeros(n_waves * 3, dtype=torch.int64, device=dev)
     assert L.rt_debug_wave_times(buf.data_ptr()) == 0
+    items = torch.zeros(3 << 20, dtype=torch.int64, device=dev)   # one record per worker batch (by first sample / 16)
+    L.rt_debug_worker_items.argtypes = [C.c_void_p]
+    assert L.rt_debug_worker_items(items.data_ptr()) == 0
     for rank in ranks:
         for rep in range(2):
             buf.zero_()
+            items.zero_()
             scene.render_pass_device(cam, w, h, min(pass_spp, spp), 0, spp, 1, tw, th, rank, a.world, out.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
         t = buf.cpu().numpy().reshape(-1, 3)
@@ -68,6 +72,18 @@ if a.wave_times:
             busy = wk[((wk[:, 2] >> 24) & 0xfffff) > 0]
             print(f"rank {rank}: {len(wk)} worker waves, {len(busy)} traced samples ({int(((busy[:, 2] >> 24) & 0xfffff).sum())} in all); they end at "
                   f"{[round(float(x)) for x in np.percentile((busy[:, 1] - t0) / 100.0, (50, 90, 100))] if len(busy) else []} us (50 / 90 / 100 %)")
+        it = items.cpu().numpy().reshape(-1, 3)
+        it = it[it[:, 1] > 0]
+        if len(it):
+            ist, idur = (it[:, 0] - t0) / 100.0, (it[:, 1] - it[:, 0]) / 100.0
+            nodes, shaded, ns = it[:, 2] & 0xffff, (it[:, 2] >> 16) & 0xffff, (it[:, 2] >> 32) & 0xff
+            print(f"rank {rank}: {len(it)} worker batches of {np.bincount(ns).nonzero()[0].tolist()} samples; us per batch 50/90/99/max "
+                  f"{[round(float(x)) for x in np.percentile(idur, (50, 90, 99, 100))]}; nodes per batch 50/90/99/max {[int(x) for x in np.percentile(nodes, (50, 90, 99, 100))]}; "
+                  f"shaded {[int(x) for x in np.percentile(shaded, (50, 90, 99, 100))]}; us per node {idur.sum() / nodes.sum():.2f}; corr(us, nodes) {np.corrcoef(idur, nodes)[0, 1]:.2f}")
+            for i in np.argsort(-(ist + idur))[:8]:
+                print(f"   batch ends {ist[i] + idur[i]:.0f} us  started {ist[i]:.0f}  ran {idur[i]:.0f} us  {nodes[i]} nodes, {shaded[i]} shaded, {ns[i]} samples, worker {it[i, 2] >> 40}")
+            late = ist > np.percentile(ist, 90)
+            print(f"   the last tenth of the batches to start: start {ist[late].min():.0f} .. {ist[late].max():.0f} us, us per batch 50/max {np.percentile(idur[late], 50):.0f} / {idur[late].max():.0f}")
         t = t[((t[:, 2] >> 44) & 0xfffff) != 0xfffff]
         st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0   # us at 100 MHz
         dur = en - st
