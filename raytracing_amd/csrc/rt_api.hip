@@ -482,6 +482,12 @@ RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ c
     return samples;
 }
 
+#ifdef RT_WALK_STATS
+extern "C" int rt_debug_walk_stats(unsigned long long* out128, int reset) {
+    if (reset) { unsigned long long z[128] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_walk), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out128, HIP_SYMBOL(rt_dbg_walk), 128 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef RT_SHADE_HIST
 extern "C" int rt_debug_shade_hist(unsigned long long* out65, int reset) {
     if (reset) { unsigned long long z[65] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_hist), z, sizeof(z)) == hipSuccess ? 0 : -1; }

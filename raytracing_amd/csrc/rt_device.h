@@ -138,6 +138,20 @@ struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris
 RT_DEV uint32_t wave_rank(uint64_t mask, uint32_t lane) {
     return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+/* The traversal stacks, the pool table and the LDS path frames are reached through these types.  Built with
+ * -DRT_LDS_TYPED they say "LDS" and every access is a ds_ instruction; by default they are generic, and where the code
+ * chooses between an LDS entry and an overflow entry the compiler merges both into one flat access.  Measured, typed
+ * against generic: 100 k-triangle frame 36.1 / 36.7 ms, 10 M-triangle frame 101.2 / 102.0 ms, but the Cornell frame
+ * 22.9 / 21.6 ms and an eighth of the 10 M-triangle frame in passes of 16 spp 36 - 41 / 21 - 23 ms: the typed build
+ * allocates registers differently and spills 976 instead of 576 bytes per lane in the variant with a BVH. */
+#ifdef RT_LDS_TYPED
+typedef __attribute__((address_space(3))) uint32_t rt_lds_u32;
+typedef __attribute__((address_space(3))) float rt_lds_f32;
+#else
+typedef uint32_t rt_lds_u32;
+typedef float rt_lds_f32;
+#endif
+RT_DEV rt_lds_u32* lds_words(uint32_t* p) { return (rt_lds_u32*)p; }
 RT_DEV void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -288,6 +302,28 @@ RT_DEV bool bvh_reaches(const DMesh& m, f3 o, f3 d, float limit) {
  * decides among four subtrees, the hit ones are visited nearest first.  Stack: RT_STACK_LDS entries in LDS, and what a
  * path could need beyond them (three pushes per level, RT_STACK_LDS / 2 levels at most) in a small per-lane array. */
 #define RT_STACK_OVER (RT_STACK_LDS / 2)
+/* The four child boxes of a wide node against a ray: how many the ray reaches within `limit`, and their stack entries
+ * (>= 0 inner node, < 0 leaf) ordered by entry distance, e0 the nearest. */
+RT_DEV int bvh4_order(const DBvh4Node& n, f3 o, f3 id, float limit, int& e0, int& e1, int& e2, int& e3) {
+    float t0, t1, t2, t3;
+    const DBvhNode& a = n.half[0];
+    const DBvhNode& b = n.half[1];
+    const bool h0 = slab(a.lo0, a.hi0, o, id, limit, t0) && !(a.n0 == 0 && a.c0 < 0);
+    const bool h1 = slab(a.lo1, a.hi1, o, id, limit, t1) && !(a.n1 == 0 && a.c1 < 0);
+    const bool h2 = slab(b.lo0, b.hi0, o, id, limit, t2) && !(b.n0 == 0 && b.c0 < 0);
+    const bool h3 = slab(b.lo1, b.hi1, o, id, limit, t3) && !(b.n1 == 0 && b.c1 < 0);
+    e0 = a.n0 > 0 ? ~(a.c0 * 8 + a.n0) : a.c0; e1 = a.n1 > 0 ? ~(a.c1 * 8 + a.n1) : a.c1;
+    e2 = b.n0 > 0 ? ~(b.c0 * 8 + b.n0) : b.c0; e3 = b.n1 > 0 ? ~(b.c1 * 8 + b.n1) : b.c1;
+    /* entry distances, +inf for a child that is not visited; sorted ascending by a five-comparator network */
+    float k0 = h0 ? t0 : RT_INF, k1 = h1 ? t1 : RT_INF, k2 = h2 ? t2 : RT_INF, k3 = h3 ? t3 : RT_INF;
+    auto order = [](float& ka, int& ea, float& kb, int& eb) {
+        const bool sw = kb < ka;
+        const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt;
+        const int et = sw ? eb : ea; eb = sw ? ea : eb; ea = et;
+    };
+    order(k0, e0, k1, e1); order(k2, e2, k3, e3); order(k0, e0, k2, e2); order(k1, e1, k3, e3); order(k1, e1, k2, e2);
+    return (int)h0 + (int)h1 + (int)h2 + (int)h3;
+}
 template <bool ANY>
 RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
                      float& best_u, float& best_v) {
@@ -298,35 +334,20 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
     uint32_t best_orig = 0xffffffffu;
     int over[RT_STACK_OVER];
     auto push = [&](int e) {
-        if (sp < RT_STACK_LDS) cnt.stack[sp * cnt.stack_stride] = (uint32_t)e; else over[(sp - RT_STACK_LDS) & (RT_STACK_OVER - 1)] = e;
+        if (sp < RT_STACK_LDS) lds_words(cnt.stack)[sp * cnt.stack_stride] = (uint32_t)e; else over[(sp - RT_STACK_LDS) & (RT_STACK_OVER - 1)] = e;
         ++sp;
     };
     auto pop = [&]() -> int {
         --sp;
-        return sp < RT_STACK_LDS ? (int)cnt.stack[sp * cnt.stack_stride] : over[(sp - RT_STACK_LDS) & (RT_STACK_OVER - 1)];
+        if (sp < RT_STACK_LDS) return (int)lds_words(cnt.stack)[sp * cnt.stack_stride];
+        return over[(sp - RT_STACK_LDS) & (RT_STACK_OVER - 1)];
     };
     int cur = m.bvh4_root;
     bool done = false;
     auto visit = [&](const DBvh4Node& n) { /* the four child boxes of one node: where to go next, what to keep for later */
         cnt.bvh_nodes += 2; /* counted in 64-byte units */
-        float t0, t1, t2, t3;
-        const DBvhNode& a = n.half[0];
-        const DBvhNode& b = n.half[1];
-        const bool h0 = slab(a.lo0, a.hi0, o, id, best_t, t0) && !(a.n0 == 0 && a.c0 < 0);
-        const bool h1 = slab(a.lo1, a.hi1, o, id, best_t, t1) && !(a.n1 == 0 && a.c1 < 0);
-        const bool h2 = slab(b.lo0, b.hi0, o, id, best_t, t2) && !(b.n0 == 0 && b.c0 < 0);
-        const bool h3 = slab(b.lo1, b.hi1, o, id, best_t, t3) && !(b.n1 == 0 && b.c1 < 0);
-        int e0 = a.n0 > 0 ? ~(a.c0 * 8 + a.n0) : a.c0, e1 = a.n1 > 0 ? ~(a.c1 * 8 + a.n1) : a.c1;
-        int e2 = b.n0 > 0 ? ~(b.c0 * 8 + b.n0) : b.c0, e3 = b.n1 > 0 ? ~(b.c1 * 8 + b.n1) : b.c1;
-        /* entry distances, +inf for a child that is not visited; sorted ascending by a five-comparator network */
-        float k0 = h0 ? t0 : RT_INF, k1 = h1 ? t1 : RT_INF, k2 = h2 ? t2 : RT_INF, k3 = h3 ? t3 : RT_INF;
-        auto order = [](float& ka, int& ea, float& kb, int& eb) {
-            const bool sw = kb < ka;
-            const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt;
-            const int et = sw ? eb : ea; eb = sw ? ea : eb; ea = et;
-        };
-        order(k0, e0, k1, e1); order(k2, e2, k3, e3); order(k0, e0, k2, e2); order(k1, e1, k3, e3); order(k1, e1, k2, e2);
-        const int hits = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+        int e0, e1, e2, e3;
+        const int hits = bvh4_order(n, o, id, best_t, e0, e1, e2, e3);
         if (hits > 3) push(e3);
         if (hits > 2) push(e2);
         if (hits > 1) push(e1);
@@ -471,6 +492,9 @@ RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt, HitRec& be
         float t;
         if (square_t(rec, o, d, t) && (best.type < 0 || t < best.t)) { best.t = t; best.type = RT_SQUARE; best.obj = (int)i; }
     });
+#ifdef RT_EXP_NO_MESH_CLOSEST
+    if (0)
+#endif
     for (uint32_t i = 0; i < sc.n_meshes; ++i) {
         float t, u, v;
         int tri;
@@ -707,7 +731,11 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
      * for a handful of them.  The rays still undecided that reach the bounds of some mesh with a BVH are reported
      * in `near` and walked later, all light samples of the shaded point together (walk_deferred). */
     near = 0;
+#ifndef RT_EXP_NO_MESH_SHADOW
     if (M & RT_M_BVH)
+#else
+    if (0)
+#endif
         for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
             const DMesh m = ldc(&sc.meshes[mi]);
             if (m.bvh_root < 0) continue;
@@ -736,14 +764,20 @@ RT_DEV f3 light_sample(const Rng& at_first, uint32_t i, f3 p0, f3 p1, f3 p2) {
 }
 
 /* The shadow rays of one shaded point that came near a mesh with a BVH (bit i of `near` = light sample i), walked
- * for all 16 light samples at once.  Such rays are rare and long (a few per hundred, ~15 nodes each), and which
- * lanes hold them is uneven: walked where they arise a wave pays a full traversal per batch for a few busy lanes.
- * So the wave's rays are numbered (lane by lane), ray g goes to the (g mod lanes)-th participating lane, round by
- * round, through the wave's own stack words in LDS, which are idle between traversals, and the answers come back
- * the same way; who walks a ray does not change its answer.  When that needs no fewer rounds than the longest
- * queue of a lane has entries, every lane walks its own.  A ray is rebuilt from the random stream where it is
- * needed (light_sample and the two normalisations of shade) instead of being kept in registers.
+ * for all 16 light samples at once.  Such rays are rare (a few per hundred), which lanes hold them is uneven, and their
+ * walks differ in length by an order of magnitude: walked where they arise, or dealt out in rounds of one ray per lane,
+ * the wave waits for its longest walk again and again (measured on the 100 k-triangle scene: 330 rays per call, the
+ * longest of a round several times the mean).  So the wave pools them: rays are numbered lane by lane, and every lane
+ * of the wave keeps taking the next unanswered ray, whoever it belongs to, until none is left; who walks a ray does
+ * not change its answer.  A ray is rebuilt from the random stream where it is needed (light_sample and the two
+ * normalisations of shade) instead of being kept in registers.
  * Returns the bits of the rays that hit a triangle before the light. */
+#ifdef RT_WALK_STATS /* debug build only: the deferred walks of a frame */
+__device__ unsigned long long rt_dbg_walk[128];
+#endif
+#define RT_POOL_ROWS 11
+#define RT_POOL_LDS (RT_STACK_LDS - RT_POOL_ROWS) /* stack entries a pooled walk keeps in LDS */
+#define RT_POOL_OVER 32                           /* ... and per lane beyond them: 21 + 32 >= three pushes per level, 16 levels */
 template <int M>
 RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_first, f3 p0, f3 p1, f3 p2, uint32_t near, Cnt& cnt) {
     const uint64_t lanes = __ballot(1);
@@ -759,6 +793,26 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
         if (__ballot(own >= t)) longest = t;
     }
     if (total == 0) return 0;
+#ifdef RT_WALK_STATS
+    const uint32_t nodes_before = cnt.bvh_nodes;
+    struct Report { /* at every return: rays and lanes of the call, the longest and the summed walk (64-byte node units) */
+        uint32_t before, total, n_lanes; const Cnt& c; unsigned long long t0; uint32_t iters, refills;
+        __device__ ~Report() {
+            const unsigned long long dt = __builtin_readcyclecounter() - t0;
+            const uint32_t mine = c.bvh_nodes - before;
+            uint32_t mx = mine, sm = mine;
+            for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64)); sm += (uint32_t)__shfl_xor((int)sm, off, 64); }
+            if (wave_rank(__ballot(1), __lane_id()) == 0u) {
+                atomicAdd(&rt_dbg_walk[0], 1ull); atomicAdd(&rt_dbg_walk[1], (unsigned long long)total); atomicAdd(&rt_dbg_walk[2], (unsigned long long)mx);
+                atomicAdd(&rt_dbg_walk[3], (unsigned long long)sm); atomicAdd(&rt_dbg_walk[4], (unsigned long long)n_lanes);
+                atomicAdd(&rt_dbg_walk[5], dt); atomicAdd(&rt_dbg_walk[6], (unsigned long long)iters); atomicAdd(&rt_dbg_walk[7], (unsigned long long)refills);
+                atomicAdd(&rt_dbg_walk[8 + min(total / 8u, 39u)], 1ull);        /* rays per call, buckets of 8 */
+                atomicAdd(&rt_dbg_walk[48 + min(mx / 16u, 39u)], 1ull);         /* longest walk, buckets of 16 units */
+                atomicAdd(&rt_dbg_walk[88 + min(total / 8u, 39u)], (unsigned long long)mx); /* longest walk summed per rays bucket */
+            }
+        }
+    } report{nodes_before, total, n_lanes, cnt, __builtin_readcyclecounter(), 0u, 0u};
+#endif
     auto ray = [&](uint32_t i, f3& d, float& dist) {
         f3 SP = light_sample(at_first, i, p0, p1, p2) - P;
         d = norm3_unit(norm3_len(SP, dist));
@@ -774,9 +828,12 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
         }
         return hit;
     };
-    uint32_t hit = 0;
-    const uint32_t rounds = (total + n_lanes - 1) / n_lanes;
-    if (rounds >= longest) { /* dealing out gains nothing */
+#ifdef RT_EXP_NO_POOL
+    if (true) {
+#else
+    if (longest <= 1) { /* at most one ray per lane: nothing to even out */
+#endif
+        uint32_t hit = 0;
         for (uint32_t bits = near; bits; bits &= bits - 1) {
             const uint32_t i = (uint32_t)__builtin_ctz(bits);
             f3 d;
@@ -786,44 +843,111 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
         }
         return hit;
     }
+    /* The pool.  Every lane leaves what a ray of its is rebuilt from in a table (the upper RT_POOL_ROWS entries of the
+     * wave's stack words; the walks keep RT_POOL_LDS entries and a longer per-lane overflow): rays before it in the wave's
+     * numbering, its mask, shaded point, origin, random stream.  Then one loop runs until every ray is answered: a lane
+     * without a ray takes the next number from a counter, finds the owner (binary search over the first row) and the
+     * sample (the k-th set bit), rebuilds the ray and starts at the root; a lane with a ray does one step, a wide node and /
+     * or a leaf.  A hit sets the sample's bit in the upper half of the owner's mask word. */
     const uint32_t lane = __lane_id();
     const uint32_t my = wave_rank(lanes, lane); /* position among the participating lanes */
-    uint32_t* const xb = cnt.stack - lane;     /* word x of the wave: xb[(x >> 6) * stride + (x & 63)] */
-    auto word = [&](uint32_t x) -> uint32_t& { return xb[(x >> 6) * cnt.stack_stride + (x & 63u)]; };
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t lo = r * n_lanes, hi = lo + n_lanes;
-        uint32_t g = start;
-        for (uint32_t bits = near; bits; bits &= bits - 1, ++g) {
-            if (g < lo || g >= hi) continue;
-            f3 d;
-            float dist;
-            ray((uint32_t)__builtin_ctz(bits), d, dist);
-            const uint32_t x = (g - lo) * 7u;
-            word(x) = __float_as_uint(o.x); word(x + 1) = __float_as_uint(o.y); word(x + 2) = __float_as_uint(o.z);
-            word(x + 3) = __float_as_uint(d.x); word(x + 4) = __float_as_uint(d.y); word(x + 5) = __float_as_uint(d.z);
-            word(x + 6) = __float_as_uint(dist);
+    rt_lds_u32* const xb = lds_words(cnt.stack) - lane;
+    const uint32_t stride = cnt.stack_stride;
+    enum { R_START = 0, R_NEAR, R_PX, R_PY, R_PZ, R_OX, R_OY, R_OZ, R_KEY, R_K, R_NEXT };
+    auto row = [&](uint32_t r, uint32_t c) -> rt_lds_u32& { return xb[(RT_POOL_LDS + r) * stride + c]; };
+    row(R_START, my) = start; row(R_NEAR, my) = near;
+    row(R_PX, my) = __float_as_uint(P.x); row(R_PY, my) = __float_as_uint(P.y); row(R_PZ, my) = __float_as_uint(P.z);
+    row(R_OX, my) = __float_as_uint(o.x); row(R_OY, my) = __float_as_uint(o.y); row(R_OZ, my) = __float_as_uint(o.z);
+    row(R_KEY, my) = at_first.key; row(R_K, my) = at_first.k;
+    if (my == 0) row(R_NEXT, 0) = n_lanes; /* rays 0 .. n_lanes - 1 are handed out by position */
+    wave_lds_sync();
+    bool want = true, out_of_rays = false, first = true;
+    uint32_t g = my, owner = 0, mi = 0;
+    f3 ro = o, rd = o, id = o;
+    float rdist = 0.f;
+    int cur = 0, sp = 0;
+    int over[RT_POOL_OVER];
+    auto push = [&](int e) {
+        if (sp < RT_POOL_LDS) lds_words(cnt.stack)[sp * stride] = (uint32_t)e; else over[(sp - RT_POOL_LDS) & (RT_POOL_OVER - 1)] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> int {
+        --sp;
+        if (sp < RT_POOL_LDS) return (int)lds_words(cnt.stack)[sp * stride];
+        return over[(sp - RT_POOL_LDS) & (RT_POOL_OVER - 1)];
+    };
+    auto next_mesh = [&](uint32_t from) { /* the first mesh with a BVH from `from` on that the ray comes near: its root, or the ray is done */
+        for (mi = from; mi < sc.n_meshes; ++mi) {
+            const DMesh m = ldc(&sc.meshes[mi]);
+            if (m.bvh_root >= 0 && bvh_reaches<true>(m, ro, rd, rdist)) { cur = m.bvh4_root; sp = 0; return true; }
         }
-        wave_lds_sync();
-        const bool mine = lo + my < total;
-        f3 o2 = o, d2 = o;
-        float dist2 = 0.f;
-        if (mine) {
-            const uint32_t x = my * 7u;
-            o2 = mk3(__uint_as_float(word(x)), __uint_as_float(word(x + 1)), __uint_as_float(word(x + 2)));
-            d2 = mk3(__uint_as_float(word(x + 3)), __uint_as_float(word(x + 4)), __uint_as_float(word(x + 5)));
-            dist2 = __uint_as_float(word(x + 6));
+        return false;
+    };
+    /* One kind of work per trip -- fetch a ray, visit a wide node, test a leaf's triangles -- and always the kind most lanes
+     * are waiting for: a lane at a leaf waits while most others still descend, and the other way round, so that each pass
+     * over the code of a kind serves many lanes (doing whatever each lane needs in every trip cost 8.5 k cycles per trip
+     * with 42 triangle tests in the 256 places of its leaf part). */
+    for (;;) {
+        const uint64_t idle = __ballot(want && !out_of_rays), inner = __ballot(!want && cur >= 0), leaf = __ballot(!want && cur < 0);
+        if (!(idle | inner | leaf)) break;
+        const uint32_t n_idle = (uint32_t)__popcll(idle), n_inner = (uint32_t)__popcll(inner), n_leaf = (uint32_t)__popcll(leaf);
+#ifdef RT_WALK_STATS
+        ++report.iters;
+        if (n_idle > n_inner && n_idle > n_leaf) ++report.refills;
+#endif
+        if (n_idle > n_inner && n_idle > n_leaf) {
+            if (want && !out_of_rays) {
+                if (!first) g = __hip_atomic_fetch_add(&row(R_NEXT, 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                first = false;
+                if (g >= total) out_of_rays = true;
+                else {
+                    uint32_t c = 0;
+#pragma unroll
+                    for (uint32_t step = 32; step; step >>= 1) {
+                        const uint32_t c2 = c + step;
+                        if (c2 < n_lanes && row(R_START, c2) <= g) c = c2;
+                    }
+                    uint32_t bits = row(R_NEAR, c) & 0xffffu;
+                    for (uint32_t k = g - row(R_START, c); k; --k) bits &= bits - 1u;
+                    const uint32_t i = (uint32_t)__builtin_ctz(bits);
+                    owner = c | (i << 8);
+                    const f3 Pc = mk3(__uint_as_float(row(R_PX, c)), __uint_as_float(row(R_PY, c)), __uint_as_float(row(R_PZ, c)));
+                    ro = mk3(__uint_as_float(row(R_OX, c)), __uint_as_float(row(R_OY, c)), __uint_as_float(row(R_OZ, c)));
+                    Rng r0; r0.key = row(R_KEY, c); r0.k = row(R_K, c);
+                    rd = norm3_unit(norm3_len(light_sample(r0, i, p0, p1, p2) - Pc, rdist));
+                    id = bvh_inv_dir(rd);
+                    want = !next_mesh(0); /* a ray that comes near no mesh after all is answered: not hit */
+                }
+            }
+        } else if (n_inner >= n_leaf) {
+            if (!want && cur >= 0) { /* a wide node */
+                const DBvh4Node n = ldc(&sc.bvh4[cur]);
+                cnt.bvh_nodes += 2;
+                int e0, e1, e2, e3;
+                const int hits = bvh4_order(n, ro, id, rdist, e0, e1, e2, e3);
+                if (hits > 3) push(e3);
+                if (hits > 2) push(e2);
+                if (hits > 1) push(e1);
+                if (hits > 0) cur = e0;
+                else if (sp > 0) cur = pop();
+                else want = !next_mesh(mi + 1u);
+            }
+        } else if (!want && cur < 0) { /* a leaf */
+            const int code = ~cur, first_tri = code >> 3, count = code & 7;
+            bool hit_now = false;
+            cnt.bvh_tris += (uint32_t)count;
+            for (int k = 0; k < count; ++k) {
+                float t, u, v;
+                if (tri_t(ldc(&sc.tris[first_tri + k]), ro, rd, t, u, v) && t > 1e-6f && t < rdist) hit_now = true;
+            }
+            if (hit_now) { __hip_atomic_fetch_or(&row(R_NEAR, owner & 0xffu), 1u << (16u + (owner >> 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); want = true; }
+            else if (sp > 0) cur = pop();
+            else want = !next_mesh(mi + 1u);
         }
-        wave_lds_sync(); /* every ray is in registers before any lane's stack overwrites the words */
-        uint32_t answer = 0;
-        if (mine) answer = any_mesh(o2, d2, dist2) ? 1u : 0u;
-        wave_lds_sync();
-        if (mine) word(my) = answer;
-        wave_lds_sync();
-        g = start;
-        for (uint32_t bits = near; bits; bits &= bits - 1, ++g)
-            if (g >= lo && g < hi && word(g - lo)) hit |= 1u << __builtin_ctz(bits);
-        wave_lds_sync();
     }
+    wave_lds_sync();
+    const uint32_t hit = row(R_NEAR, my) >> 16;
+    wave_lds_sync(); /* every lane has its answer before the words are stack entries again */
     return hit;
 }
 
@@ -904,6 +1028,9 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     if (M & RT_M_BVH) {
                         if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;
                         now = first_open == 16;
+#ifdef RT_EXP_ALWAYS_NOW
+                        now = true;
+#endif
 #pragma unroll
                         for (int j = 0; j < RT_SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
                         near |= near4 << i0;
@@ -914,10 +1041,20 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                             if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
                     }
                 }
+#ifdef RT_EXP_ALWAYS_NOW
+                if ((M & RT_M_BVH) && first_open < 16) {
+                    if (__ballot(near != 0)) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
+                    if (dark == 0x12345u) sum.x += 1.f;
+                } else
+#endif
                 if ((M & RT_M_BVH) && first_open < 16) {
                     /* the undecided rays of all samples in one go, then the rest of the sum in sample order; a light direction
                      * is cheaper to rebuild from the random stream than to keep over the traversals */
+#ifdef RT_EXP_NEVER_WALK
+                    if (__ballot(near != 0) && sc.n_meshes > 1000u) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
+#elif !defined(RT_EXP_NO_WALK)
                     if (__ballot(near != 0)) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
+#endif
                     for (uint32_t i = first_open; i < 16; ++i) {
                         if ((dark >> i) & 1u) continue;
                         float len;
@@ -1022,7 +1159,7 @@ RT_DEV Bounce bounce_rays(const DeviceScene& sc, int mtype, int mat, f3 P, f3 N,
 #define RT_FRAME_WORDS 7
 template <int L>
 struct FrameStack {
-    float* lds; uint32_t stride;
+    rt_lds_f32* lds; uint32_t stride; /* the LDS levels, typed as LDS (see lds_words) */
     float deep[(RT_MAX_BOUNCES - L > 0 ? RT_MAX_BOUNCES - L : 1) * RT_FRAME_WORDS];
     /* N words of level l, from / into v[first .. first + N) */
     template <int FIRST, int N>
@@ -1049,7 +1186,7 @@ struct FrameStack {
 template <int M, bool PROBE = false, int L = 0>
 RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
     FrameStack<L> stk;
-    stk.lds = cnt.frames; stk.stride = cnt.frame_stride;
+    stk.lds = (rt_lds_f32*)cnt.frames; stk.stride = cnt.frame_stride;
     int sp = 0;
     uint32_t kinds = 0; /* bits 2 l, 2 l + 1: kind of the frame at level l */
     f3 ret = mk3(0.f, 0.f, 0.f);

@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from raytracing_amd import api, host, parallel_render, workloads  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--config", required=True, choices=["c4", "c5"])
+ap.add_argument("--config", required=True, choices=["c2", "c3", "c4", "c5"])
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--ranks", default="")
 ap.add_argument("--spp", type=int, default=0)
