@@ -796,7 +796,7 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
 #ifdef RT_WALK_STATS
     const uint32_t nodes_before = cnt.bvh_nodes;
     struct Report { /* at every return: rays and lanes of the call, the longest and the summed walk (64-byte node units) */
-        uint32_t before, total, n_lanes; const Cnt& c; unsigned long long t0; uint32_t iters, refills;
+        uint32_t before, total, n_lanes; const Cnt& c; unsigned long long t0; uint32_t iters, refills; uint32_t last_kind; unsigned long long last_t; unsigned long long k_cycles[3]; uint32_t k_trips[3], k_lanes[3];
         __device__ ~Report() {
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
             const uint32_t mine = c.bvh_nodes - before;
@@ -805,13 +805,17 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
             if (wave_rank(__ballot(1), __lane_id()) == 0u) {
                 atomicAdd(&rt_dbg_walk[0], 1ull); atomicAdd(&rt_dbg_walk[1], (unsigned long long)total); atomicAdd(&rt_dbg_walk[2], (unsigned long long)mx);
                 atomicAdd(&rt_dbg_walk[3], (unsigned long long)sm); atomicAdd(&rt_dbg_walk[4], (unsigned long long)n_lanes);
+                for (int k = 0; k < 3; ++k) {
+                    atomicAdd(&rt_dbg_walk[114 + k], (unsigned long long)k_trips[k]); atomicAdd(&rt_dbg_walk[117 + k], (unsigned long long)k_lanes[k]);
+                    atomicAdd(&rt_dbg_walk[120 + k], k_cycles[k]);
+                }
                 atomicAdd(&rt_dbg_walk[5], dt); atomicAdd(&rt_dbg_walk[6], (unsigned long long)iters); atomicAdd(&rt_dbg_walk[7], (unsigned long long)refills);
                 atomicAdd(&rt_dbg_walk[8 + min(total / 8u, 39u)], 1ull);        /* rays per call, buckets of 8 */
                 atomicAdd(&rt_dbg_walk[48 + min(mx / 16u, 39u)], 1ull);         /* longest walk, buckets of 16 units */
-                atomicAdd(&rt_dbg_walk[88 + min(total / 8u, 39u)], (unsigned long long)mx); /* longest walk summed per rays bucket */
+                atomicAdd(&rt_dbg_walk[88 + min(total / 16u, 25u)], (unsigned long long)mx); /* longest walk summed per rays bucket */
             }
         }
-    } report{nodes_before, total, n_lanes, cnt, __builtin_readcyclecounter(), 0u, 0u};
+    } report{nodes_before, total, n_lanes, cnt, __builtin_readcyclecounter(), 0u, 0u, 3u, 0ull, {0ull, 0ull, 0ull}, {0u, 0u, 0u}, {0u, 0u, 0u}};
 #endif
     auto ray = [&](uint32_t i, f3& d, float& dist) {
         f3 SP = light_sample(at_first, i, p0, p1, p2) - P;
@@ -894,6 +898,14 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
 #ifdef RT_WALK_STATS
         ++report.iters;
         if (n_idle > n_inner && n_idle > n_leaf) ++report.refills;
+        { /* cycles and lanes served per kind of trip: [16 + 3 kind] trips, [17 + 3 kind] lanes, [18 + 3 kind] cycles (of the trip before) */
+            const unsigned long long now = __builtin_readcyclecounter();
+            const uint32_t kind = (n_idle > n_inner && n_idle > n_leaf) ? 0u : (n_inner >= n_leaf ? 1u : 2u);
+            if (report.last_kind < 3u) report.k_cycles[report.last_kind] += now - report.last_t;
+            report.k_trips[kind] += 1u;
+            report.k_lanes[kind] += kind == 0u ? n_idle : (kind == 1u ? n_inner : n_leaf);
+            report.last_kind = kind; report.last_t = now;
+        }
 #endif
         if (n_idle > n_inner && n_idle > n_leaf) {
             if (want && !out_of_rays) {

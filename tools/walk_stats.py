@@ -37,10 +37,13 @@ print(f"{int(calls)} walk calls ({calls / (st.nodes / 64):.2f} per 64 shaded nod
       f"lane use during the walks {sm / (mx * 64) * 100:.1f} %")
 print(f"shader cycles inside the walk calls: {h[5]:.3e} = {h[5] / calls:.0f} per call ({h[5] / 2.4e9 / 4096 * 1e3:.2f} ms of all 4096 wave slots at 2.4 GHz); "
       f"pool loop: {h[6] / calls:.1f} iterations and {h[7] / calls:.1f} fetch phases per call, {h[5] / max(h[6], 1):.0f} cycles per iteration")
-print("rays per call: share of calls, mean longest walk")
+for k, name in enumerate(("fetch a ray", "visit a wide node", "test a leaf")):
+    if h[114 + k]:
+        print(f"  trips that {name:18s}: {h[114 + k] / calls:6.1f} per call, {h[117 + k] / h[114 + k]:5.1f} lanes served, {h[120 + k] / h[114 + k]:6.0f} cycles each")
+print("rays per call: share of calls")
 for b in range(40):
     if h[8 + b]:
-        print(f"  {8 * b:3d}..{8 * b + 7:3d}{'+' if b == 39 else ' '}: {h[8 + b] / calls * 100:6.2f} %   {h[88 + b] / h[8 + b]:7.1f}")
+        print(f"  {8 * b:3d}..{8 * b + 7:3d}{'+' if b == 39 else ' '}: {h[8 + b] / calls * 100:6.2f} %")
 print("longest walk of a call (64-byte node units): share of calls")
 for b in range(40):
     if h[48 + b]:
