@@ -327,7 +327,7 @@ RT_DEV int bvh4_order(const DBvh4Node& n, f3 o, f3 id, float limit, int& e0, int
 template <bool ANY>
 RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
                      float& best_u, float& best_v) {
-    best_t = ANY ? dist : 3.402823466e+38f; /* FLT_MAX, the reference's initial closest t */
+    best_t = dist; /* ANY: the distance to the light; closest hit: FLT_MAX, the reference's initial closest t, or what a hit has to beat */
     const f3 id = bvh_inv_dir(d);
     int sp = 0;
     bool found = false;
@@ -386,15 +386,20 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
 template <bool ANY>
 RT_DEV bool bvh_traverse(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
                          float& best_u, float& best_v) {
-    best_t = ANY ? dist : 3.402823466e+38f;
-    if (!bvh_reaches<ANY>(m, o, d, best_t)) return false;
+    best_t = dist;
+    if (!bvh_reaches<true>(m, o, d, best_t)) return false; /* the bounds within `dist`, for either kind of query */
     return bvh_walk<ANY>(sc, m, o, d, dist, cnt, best_t, best_tri, best_u, best_v);
 }
 
 /* ---- Mesh::intersect closest loop, R/src/Mesh.h:225-277 (brute force over the slice) ----- */
+/* `limit`: the caller only uses a hit with t < limit (the closest hit among the objects tested before), so a mesh with
+ * a BVH is walked no further than that: a ray inside the glass sphere, or one that ends on the mirror sphere in front of
+ * the mesh, fetches no node at all.  A hit the brute-force loop would report beyond the limit is not reported, which
+ * the caller cannot tell apart. */
 template <int M>
-RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, Cnt& cnt, float& best_t, int& best_tri, float& best_u, float& best_v) {
-    if ((M & RT_M_BVH) && m.bvh_root >= 0) return bvh_traverse<false>(sc, m, o, d, 0.f, cnt, best_t, best_tri, best_u, best_v);
+RT_DEV bool mesh_closest(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, Cnt& cnt, float& best_t, int& best_tri, float& best_u, float& best_v,
+                         float limit = 3.402823466e+38f) {
+    if ((M & RT_M_BVH) && m.bvh_root >= 0) return bvh_traverse<false>(sc, m, o, d, limit, cnt, best_t, best_tri, best_u, best_v);
     bool found = false;
     best_t = 3.402823466e+38f; /* FLT_MAX */
     for (uint32_t i = 0; i < m.n_tris; ++i) {
@@ -498,7 +503,7 @@ RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt, HitRec& be
     for (uint32_t i = 0; i < sc.n_meshes; ++i) {
         float t, u, v;
         int tri;
-        if (mesh_closest<M>(sc, ldc(&sc.meshes[i]), o, d, cnt, t, tri, u, v) && (best.type < 0 || t < best.t)) {
+        if (mesh_closest<M>(sc, ldc(&sc.meshes[i]), o, d, cnt, t, tri, u, v, best.type < 0 ? 3.402823466e+38f : best.t) && (best.type < 0 || t < best.t)) {
             best.t = t; best.type = RT_MESH; best.obj = (int)i; best.tri = tri; best.u = u; best.v = v;
         }
     }
