@@ -364,14 +364,22 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
             int code = ~cur;
             int first = code >> 3, count = code & 7;
             cnt.bvh_tris += (uint32_t)count;
-            for (int k = 0; k < count; ++k) {
-                float t, u, v;
-                if (tri_t(ldc(&sc.tris[first + k]), o, d, t, u, v) && t > 1e-6f) {
-                    if (ANY) { if (t < dist) return true; }
-                    else if (t <= best_t) { /* the original index is only needed to break a tie */
-                        uint32_t orig = ldc(&sc.tri_orig[first + k]);
-                        if (t < best_t || orig < best_orig) {
-                            best_t = t; best_tri = first + k; best_u = u; best_v = v; best_orig = orig; found = true;
+            /* two records per round, both requested before the first is used */
+            for (int k0 = 0; k0 < count; k0 += 2) {
+                const int k1 = k0 + 1 < count ? k0 + 1 : k0;
+                const DTri ta = ldc(&sc.tris[first + k0]);
+                const DTri tb = ldc(&sc.tris[first + k1]);
+                for (int j = 0; j < 2; ++j) {
+                    const int k = j ? k1 : k0;
+                    if (j && k1 == k0) break;
+                    float t, u, v;
+                    if (tri_t(j ? tb : ta, o, d, t, u, v) && t > 1e-6f) {
+                        if (ANY) { if (t < dist) return true; }
+                        else if (t <= best_t) { /* the original index is only needed to break a tie */
+                            uint32_t orig = ldc(&sc.tri_orig[first + k]);
+                            if (t < best_t || orig < best_orig) {
+                                best_t = t; best_tri = first + k; best_u = u; best_v = v; best_orig = orig; found = true;
+                            }
                         }
                     }
                 }
@@ -953,9 +961,25 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
             const int code = ~cur, first_tri = code >> 3, count = code & 7;
             bool hit_now = false;
             cnt.bvh_tris += (uint32_t)count;
-            for (int k = 0; k < count; ++k) {
-                float t, u, v;
-                if (tri_t(ldc(&sc.tris[first_tri + k]), ro, rd, t, u, v) && t > 1e-6f && t < rdist) hit_now = true;
+            /* two records per round, both requested before the first is used, and tri_t's arithmetic without its early
+             * returns (the same operations on the same values; a test that tri_t leaves early fails here in its condition) */
+            auto hits = [&](const DTri& tr) {
+                const f3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+                const f3 h = cross3(rd, e2);
+                const float a = dot3(e1, h);
+                const float f = 1.0f / a;
+                const f3 sv = ro - ld3(tr.v0);
+                const float u = f * dot3(sv, h);
+                const f3 q = cross3(sv, e1);
+                const float v = f * dot3(rd, q);
+                const float t = f * dot3(e2, q);
+                return !(__builtin_fabsf(a) < 1e-6f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && t > 1e-6f && t < rdist;
+            };
+            for (int k = 0; k < count; k += 2) {
+                const DTri ta = ldc(&sc.tris[first_tri + k]);
+                const DTri tb = ldc(&sc.tris[first_tri + (k + 1 < count ? k + 1 : k)]);
+                const bool ha = hits(ta), hb = hits(tb);
+                hit_now = hit_now || ha || hb;
             }
             if (hit_now) { __hip_atomic_fetch_or(&row(R_NEAR, owner & 0xffu), 1u << (16u + (owner >> 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); want = true; }
             else if (sp > 0) cur = pop();
