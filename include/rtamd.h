@@ -205,6 +205,19 @@ int rt_set_option(const char* name, int64_t value);
 int rt_selftest_arith(uint64_t n, uint32_t seed, uint64_t* mismatches);
 
 /* ---- scene -------------------------------------------------------------------------------- */
+/* New vertex positions and normals for the meshes of a scene whose triangles stay the same (a deforming or moving
+ * mesh): the triangle records, the boxes of every BVH node (binary and four-wide tables) and the bounds of the meshes
+ * and of the scene are recomputed on the device; the trees keep their shape and the records their order.
+ * positions / normals: n_vertices x 3 floats laid out like rt_scene_desc.positions / .normals (host pointers),
+ * n_vertices as at creation.  Queries after the call answer for the new geometry exactly as a scene created from it
+ * would (same hit records, same images); a tree refitted over a strongly deformed mesh is merely slower to walk.
+ * Only for scenes whose object kd-tree is one leaf because of their object count (at most kd_max_leaf objects, 30 in the
+ * reference): RT_E_INVALID otherwise.  device_ms (may be null):
+ * GPU time of the call.  No counterpart in the reference, where nothing moves: it is the companion of the tree build
+ * on the GPU, for callers that animate a mesh between frames.  Blocks until done; not to be called while a render of
+ * the scene is in flight. */
+int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normals, uint32_t n_vertices, float* device_ms);
+
 /* Copy the scene, build the object-level kd-tree (R/src/KDTree.cpp:363-519, done on the host as
  * Scene::buildKDTree does) and the per-mesh triangle BVH, upload everything.  Stands in for the
  * state left by Scene::setup_* + Scene::buildKDTree (R/src/Scene.h:112-115, 722-1048). */

@@ -79,7 +79,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
                       ("n", "<f4", 3), ("pad2", "<f4")])
 
 # every symbol include/rtamd.h declares
-EXPORTS = ["rt_init", "rt_set_option", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_destroy", "rt_scene_kdtree",
+EXPORTS = ["rt_init", "rt_set_option", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_refit", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_primitive_intersect", "rt_comm_unique_id", "rt_comm_init",
            "rt_comm_destroy", "rt_comm_rank", "rt_comm_world", "rt_gather_tiles_device", "rt_render_sharded", "rt_generate_rays", "rt_trace",
            "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_render_device_noalloc", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
@@ -103,6 +103,7 @@ def lib():
         L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(u64)]
         L.rt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), u32, C.POINTER(u64)]
         L.rt_scene_verify.argtypes = [u64, C.POINTER(BuildInfo), C.POINTER(BuildTimes)]
+        L.rt_scene_refit.argtypes = [u64, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
         L.rt_scene_destroy.argtypes = [u64]
         L.rt_scene_kdtree.argtypes = [u64, vp, C.POINTER(u32), vp, C.POINTER(u32), vp]
         L.rt_intersect.argtypes = [u64, vp, vp, C.c_size_t, vp]
@@ -202,6 +203,15 @@ class DeviceScene:
         info, times = BuildInfo(), BuildTimes()
         check(lib().rt_scene_verify(self.h, C.byref(info), C.byref(times)))
         return info, times
+
+    def refit(self, positions, normals):
+        """rt_scene_refit: new vertex positions / normals (n_vertices x 3 float32 each), same triangles; returns the GPU ms."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        assert pos.shape == nrm.shape
+        ms = C.c_float(0.0)
+        check(lib().rt_scene_refit(self.h, pos.ctypes.data, nrm.ctypes.data, len(pos), C.byref(ms)))
+        return ms.value
 
     def close(self):
         if self.h:

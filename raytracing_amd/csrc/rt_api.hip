@@ -820,6 +820,10 @@ struct SceneRes {
     int bvh_depth = 0;
     rt_build_times times{};
     std::vector<void*> allocs;
+    /* for rt_scene_refit: the vertex slice of every mesh, and the box of everything that is not a mesh */
+    std::vector<std::pair<uint32_t, uint32_t>> mesh_vertices;
+    float static_lo[3] = {INFINITY, INFINITY, INFINITY}, static_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool leaf_by_count = false; /* the kd root is a leaf whatever the bounds of the objects are */
 };
 
 const unsigned kCamSlots = 64;
@@ -1209,6 +1213,21 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
         const int mt = r->host.materials[(size_t)sp.mat].type;
         r->has_bounce = r->has_bounce || mt == RT_MAT_MIRROR || mt == RT_MAT_GLASS;
     }
+    for (uint32_t i = 0; i < desc->n_meshes; ++i) r->mesh_vertices.push_back({desc->meshes[i].first_vertex, desc->meshes[i].n_vertices});
+    r->leaf_by_count = (int64_t)r->host.refs.size() <= (int64_t)desc->kd_max_leaf || desc->kd_max_depth <= 0;
+    { /* Scene::computeGlobalAABB's contributions of squares and spheres (R/src/Scene.h:133-166), as rtb::build_scene adds them */
+        auto grow = [&](const float* p) {
+            for (int a = 0; a < 3; ++a) { r->static_lo[a] = (p[a] < r->static_lo[a]) ? p[a] : r->static_lo[a]; r->static_hi[a] = (r->static_hi[a] < p[a]) ? p[a] : r->static_hi[a]; }
+        };
+        for (uint32_t i = 0; i < desc->n_squares; ++i)
+            for (int v = 0; v < 4; ++v) grow(desc->squares[i].v[v]);
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            const rt_sphere& sp = desc->spheres[i];
+            const float lo[3] = {sp.center[0] - sp.radius, sp.center[1] - sp.radius, sp.center[2] - sp.radius};
+            const float hi[3] = {sp.center[0] + sp.radius, sp.center[1] + sp.radius, sp.center[2] + sp.radius};
+            grow(lo); grow(hi);
+        }
+    }
     /* the big tables now live on the device only (rt_scene_verify reads them back) */
     std::vector<DTri>().swap(r->host.tris);
     std::vector<uint32_t>().swap(r->host.tri_orig);
@@ -1270,6 +1289,71 @@ int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times
                              r->host.kd.size() * sizeof(DKdNode) + r->host.refs.size() * sizeof(DRef);
     }
     if (times) *times = r->times;
+    return RT_OK;
+}
+
+int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normals, uint32_t n_vertices, float* device_ms) {
+    SceneRes* r = find(scene);
+    if (!r) return fail(RT_E_HANDLE, "rt_scene_refit: unknown scene");
+    if (!positions || !normals) return fail(RT_E_INVALID, "rt_scene_refit: null argument");
+    if ((size_t)n_vertices * 3 != r->n_normals) return fail(RT_E_INVALID, "rt_scene_refit: the scene was made with another number of vertices");
+    if (!r->dev.root_is_leaf || !r->leaf_by_count)
+        return fail(RT_E_INVALID, "rt_scene_refit: the object kd-tree of this scene depends on the mesh bounds (more objects than a leaf holds): make the scene again");
+    if (device_ms) *device_ms = 0.f;
+    if (n_vertices == 0 || r->host.meshes.empty()) return RT_OK;
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    const size_t n_mesh = r->host.meshes.size();
+    Scratch tmp;
+    float* d_pos; uint32_t* d_box;
+    int rc;
+    if ((rc = tmp.get((void**)&d_pos, (size_t)n_vertices * 12)) || (rc = tmp.get((void**)&d_box, n_mesh * 64))) return rc;
+    std::vector<uint32_t> boxes(n_mesh * 16); /* per mesh: the box of its records' corners, the box of its raw vertices */
+    for (size_t k = 0; k < 2 * n_mesh; ++k) rtd::box_init(&boxes[8 * k]);
+    HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_pos, positions, (size_t)n_vertices * 12, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(const_cast<float*>(r->dev.normals), normals, (size_t)n_vertices * 12, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_box, boxes.data(), n_mesh * 64, hipMemcpyHostToDevice, g.stream));
+    for (size_t k = 0; k < n_mesh; ++k) {
+        const DMesh& m = r->host.meshes[k];
+        HIP_TRY(rtd::remake_mesh_tris(d_pos, n_vertices, const_cast<DTri*>(r->dev.tris) + m.first_tri, m.n_tris, d_box + 16 * k, g.stream));
+        HIP_TRY(rtd::vertex_box(d_pos + 3 * (size_t)r->mesh_vertices[k].first, r->mesh_vertices[k].second, d_box + 16 * k + 8, g.stream));
+    }
+    HIP_TRY(hipMemcpyAsync(boxes.data(), d_box, n_mesh * 64, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    /* bounds of every mesh and of the scene, as a fresh build computes them */
+    float root_lo[3], root_hi[3];
+    for (int a = 0; a < 3; ++a) { root_lo[a] = r->static_lo[a]; root_hi[a] = r->static_hi[a]; }
+    std::vector<int32_t> roots;
+    std::vector<float> pads;
+    for (size_t k = 0; k < n_mesh; ++k) {
+        float lo[3], hi[3];
+        bool bad = false;
+        rtd::box_decode(&boxes[16 * k], lo, hi, bad);
+        if (bad) return fail(RT_E_INVALID, "rt_scene_refit: a triangle record holds a vertex id outside the vertex pool");
+        DMesh& m = r->host.meshes[k];
+        const float pad = rtb::mesh_bounds_from_box(lo, hi, m.n_tris, m);
+        if (m.bvh_root >= 0) { roots.push_back(m.bvh_root); pads.push_back(pad); }
+        rtd::box_decode(&boxes[16 * k + 8], lo, hi, bad);
+        for (int a = 0; a < 3; ++a) { root_lo[a] = (lo[a] < root_lo[a]) ? lo[a] : root_lo[a]; root_hi[a] = (root_hi[a] < hi[a]) ? hi[a] : root_hi[a]; }
+    }
+    std::string err;
+    hipError_t e = rtd::refit_bvh2(const_cast<DBvhNode*>(r->dev.bvh), (uint32_t)r->n_bvh, roots.data(), pads.data(), (uint32_t)roots.size(), r->dev.tris, g.stream, err);
+    if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_refit: " + err);
+    if (r->n_bvh) {
+        std::vector<int32_t> roots4(roots.size(), -1);
+        DBvh4Node* same = nullptr;
+        uint32_t n4 = 0;
+        e = rtd::collapse_to_bvh4(r->dev.bvh, (uint32_t)r->n_bvh, roots.data(), (uint32_t)roots.size(), g.stream, &same, &n4, roots4.data(), err,
+                                  const_cast<DBvh4Node*>(r->dev.bvh4), (uint32_t)r->n_bvh4);
+        if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_refit: " + err);
+    }
+    HIP_TRY(hipMemcpyAsync(const_cast<DMesh*>(r->dev.meshes), r->host.meshes.data(), n_mesh * sizeof(DMesh), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipEventRecord(g.ev1, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (device_ms) HIP_TRY(hipEventElapsedTime(device_ms, g.ev0, g.ev1));
+    for (int a = 0; a < 3; ++a) { r->host.box_lo[a] = r->dev.box_lo[a] = root_lo[a]; r->host.box_hi[a] = r->dev.box_hi[a] = root_hi[a]; }
+    g.order_last_slot = -1; /* a launch order or deep list probed before the vertices moved is not used again */
     return RT_OK;
 }
 

@@ -42,9 +42,24 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
 /* The four-wide form of a table of binary trees (DBvh4Node, rt_types.h): every node at an even depth of its tree is
  * kept and takes over the children of its inner children.  d_bvh2[0, n2): the binary nodes of all meshes (child
  * indices into the same table); roots[0, n_roots): the root nodes, roots4 gets their positions in the new table.
- * The new table comes back in a fresh device array (hipFree by the caller).  Blocks until done. */
+ * The new table comes back in a fresh device array (hipFree by the caller) -- or, when `existing` is given (a table of
+ * n_existing nodes made from the same trees: a refit), in that one.  Blocks until done. */
 hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, uint32_t n_roots, hipStream_t stream,
-                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err);
+                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err, DBvh4Node* existing = nullptr,
+                            uint32_t n_existing = 0);
+
+/* Refit: the vertices moved, the triangles and the trees stay.
+ * vertex_box: exact box of `count` raw positions into d_box (8 words, box_init / box_decode).
+ * remake_mesh_tris: the `count` records at d_tris (any order -- after a build, leaf order) again from the vertex ids they
+ *   carry and the new positions (d_positions = the scene's whole vertex pool of n_vertices), with the box of their corners
+ *   in d_box as make_mesh_tris leaves it.
+ * refit_bvh2: the child boxes of every node under the given roots, deepest level first, from the new records: a
+ *   leaf's triangles padded by its tree's pad (pads[k] belongs to roots[k]), an inner child's two boxes joined.
+ *   Blocks until done.  The four-wide table follows with collapse_to_bvh4(.., existing table). */
+hipError_t vertex_box(const float* d_positions, uint32_t count, uint32_t* d_box, hipStream_t stream);
+hipError_t remake_mesh_tris(const float* d_positions, uint32_t n_vertices, DTri* d_tris, uint32_t count, uint32_t* d_box, hipStream_t stream);
+hipError_t refit_bvh2(DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, const float* pads, uint32_t n_roots, const DTri* d_tris, hipStream_t stream,
+                      std::string& err);
 
 }  // namespace rtd
 #endif

@@ -298,6 +298,95 @@ __global__ void __launch_bounds__(256) k_collapse(const DBvhNode* nodes, uint32_
     out[rank[i]] = o;
 }
 
+/* ---- refit: new vertex positions, same triangles, same trees ------------------------------------------------- */
+/* exact box of the raw positions of one mesh's vertices (what Scene::computeGlobalAABB grows the root box by) */
+__global__ void __launch_bounds__(256) k_vertex_box(const float* positions, uint32_t count, uint32_t* box) {
+    __shared__ float s_box[4][6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint64_t v = (uint64_t)blockIdx.x * 256u + threadIdx.x; v < count; v += (uint64_t)gridDim.x * 256u)
+        for (int a = 0; a < 3; ++a) { const float p = positions[3 * v + a]; lo[a] = fminf(lo[a], p); hi[a] = fmaxf(hi[a], p); }
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    if ((threadIdx.x & 63u) == 0)
+        for (int a = 0; a < 3; ++a) { s_box[threadIdx.x >> 6][a] = lo[a]; s_box[threadIdx.x >> 6][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = (int)threadIdx.x;
+        float v = s_box[0][k];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? fminf(v, s_box[w][k]) : fmaxf(v, s_box[w][k]);
+        if (k < 3) atomicMin(&box[k], ordered(v)); else atomicMax(&box[k], ordered(v));
+    }
+}
+
+/* The records of one mesh again, in the order they have (leaf order), from the vertex ids each record carries: the
+ * arithmetic of k_make_tris on the new positions (the whole vertex pool: the ids are global), and the box of the corners. */
+__global__ void __launch_bounds__(256) k_remake_tris(const float* positions, uint32_t n_vertices, DTri* tris, uint32_t count, uint32_t* box) {
+    __shared__ float s_box[4][6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < count; t += (uint64_t)gridDim.x * 256u) {
+        DTri tr = tris[t];
+        if (tr.i0 >= n_vertices || tr.i1 >= n_vertices || tr.i2 >= n_vertices) { atomicOr(&box[6], 1u); continue; }
+        const float scaling = 1.000001f; /* R/src/Mesh.h:220 */
+        const float* p0 = positions + 3 * (size_t)tr.i0;
+        const float* p1 = positions + 3 * (size_t)tr.i1;
+        const float* p2 = positions + 3 * (size_t)tr.i2;
+        for (int a = 0; a < 3; ++a) {
+            const float v0 = scaling * p0[a], v1 = scaling * p1[a], v2 = scaling * p2[a];
+            tr.v0[a] = v0; tr.e1[a] = v1 - v0; tr.e2[a] = v2 - v0;
+        }
+        tri_box(tr, lo, hi);
+        tris[t] = tr;
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    if ((threadIdx.x & 63u) == 0)
+        for (int a = 0; a < 3; ++a) { s_box[threadIdx.x >> 6][a] = lo[a]; s_box[threadIdx.x >> 6][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = (int)threadIdx.x;
+        float v = s_box[0][k];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? fminf(v, s_box[w][k]) : fmaxf(v, s_box[w][k]);
+        if (k < 3) atomicMin(&box[k], ordered(v)); else atomicMax(&box[k], ordered(v));
+    }
+}
+
+/* depth of every node below its root, and which of the given roots that is (255: none of them) */
+__global__ void __launch_bounds__(256) k_depth_owner(const int32_t* parent, uint32_t n2, const int32_t* roots, uint32_t n_roots, uint8_t* depth, uint8_t* owner) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n2) return;
+    uint32_t d = 0;
+    int32_t top = (int32_t)i;
+    for (int32_t p = parent[i]; p >= 0 && d < 255u; p = parent[p]) { ++d; top = p; }
+    uint32_t o = 255u;
+    for (uint32_t k = 0; k < n_roots && k < 255u; ++k) if (roots[k] == top) o = k;
+    depth[i] = (uint8_t)d; owner[i] = (uint8_t)o;
+}
+
+/* the two child boxes of every node of one level, as k_fit makes them: a leaf's triangles and the pad, or the union of
+ * an inner child's (already refitted, padded) boxes */
+__global__ void __launch_bounds__(256) k_refit_level(DBvhNode* nodes, uint32_t n2, const uint8_t* depth, const uint8_t* owner, uint32_t level,
+                                                     const DTri* tris, const float* pads) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n2 || depth[i] != level || owner[i] == 255u) return;
+    DBvhNode n = nodes[i];
+    const float pad = pads[owner[i]];
+    float* olo[2] = {n.lo0, n.lo1};
+    float* ohi[2] = {n.hi0, n.hi1};
+    const int32_t c[2] = {n.c0, n.c1}, cnt[2] = {n.n0, n.n1};
+    for (int k = 0; k < 2; ++k) {
+        if (child_empty(c[k], cnt[k])) continue;
+        if (child_inner(c[k], cnt[k])) {
+            const DBvhNode ch = nodes[c[k]];
+            for (int a = 0; a < 3; ++a) { olo[k][a] = fminf(ch.lo0[a], ch.lo1[a]); ohi[k][a] = fmaxf(ch.hi0[a], ch.hi1[a]); }
+        } else {
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int32_t t = c[k]; t < c[k] + cnt[k]; ++t) tri_box(tris[t], blo, bhi);
+            for (int a = 0; a < 3; ++a) { olo[k][a] = blo[a] - pad; ohi[k][a] = bhi[a] + pad; }
+        }
+    }
+    nodes[i] = n;
+}
+
 struct Temps {
     std::vector<void*> ptrs;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -442,7 +531,7 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
 }
 
 hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, uint32_t n_roots, hipStream_t stream,
-                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err) {
+                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err, DBvh4Node* existing, uint32_t n_existing) {
     *d_bvh4 = nullptr; *n4 = 0;
     if (n2 == 0) return hipSuccess;
     Temps tmp;
@@ -468,13 +557,54 @@ hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* 
         BVH_TRY(hipMemcpyAsync(&roots4[k], rank + roots[k], 4, hipMemcpyDeviceToHost, stream));
     }
     BVH_TRY(hipStreamSynchronize(stream));
-    DBvh4Node* out = nullptr;
-    BVH_TRY(hipMalloc((void**)&out, (size_t)(total ? total : 1) * sizeof(DBvh4Node)));
+    DBvh4Node* out = existing;
+    if (existing && n_existing != total) { err = "four-wide BVH: the table to refresh has another size"; return hipErrorInvalidValue; }
+    if (!existing) BVH_TRY(hipMalloc((void**)&out, (size_t)(total ? total : 1) * sizeof(DBvh4Node)));
     hipLaunchKernelGGL(k_collapse, dim3(blocks(n2)), dim3(256), 0, stream, d_bvh2, n2, (const uint32_t*)keep, (const uint32_t*)rank, out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) { (void)hipFree(out); err = std::string("four-wide BVH: ") + hipGetErrorString(e); return e; }
+    if (e != hipSuccess) { if (!existing) (void)hipFree(out); err = std::string("four-wide BVH: ") + hipGetErrorString(e); return e; }
     *d_bvh4 = out; *n4 = total;
+    return hipSuccess;
+}
+
+hipError_t vertex_box(const float* d_positions, uint32_t count, uint32_t* d_box, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const unsigned grid = blocks(count) < 1024u ? blocks(count) : 1024u;
+    hipLaunchKernelGGL(k_vertex_box, dim3(grid), dim3(256), 0, stream, d_positions, count, d_box);
+    return hipGetLastError();
+}
+
+hipError_t remake_mesh_tris(const float* d_positions, uint32_t n_vertices, DTri* d_tris, uint32_t count, uint32_t* d_box, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const unsigned grid = blocks(count) < 4096u ? blocks(count) : 4096u;
+    hipLaunchKernelGGL(k_remake_tris, dim3(grid), dim3(256), 0, stream, d_positions, n_vertices, d_tris, count, d_box);
+    return hipGetLastError();
+}
+
+hipError_t refit_bvh2(DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, const float* pads, uint32_t n_roots, const DTri* d_tris, hipStream_t stream,
+                      std::string& err) {
+    if (n2 == 0 || n_roots == 0) return hipSuccess;
+    if (n_roots > 254u) { err = "BVH refit: more than 254 meshes with a BVH"; return hipErrorInvalidValue; }
+    Temps tmp;
+    int32_t *parent, *d_roots;
+    uint8_t *depth, *owner;
+    float* d_pads;
+    BVH_TRY(tmp.get(&parent, n2)); BVH_TRY(tmp.get(&depth, n2)); BVH_TRY(tmp.get(&owner, n2));
+    BVH_TRY(tmp.get(&d_roots, n_roots)); BVH_TRY(tmp.get(&d_pads, n_roots));
+    BVH_TRY(hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 4, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipMemcpyAsync(d_pads, pads, (size_t)n_roots * 4, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipMemsetAsync(parent, 0xff, (size_t)n2 * 4, stream));
+    hipLaunchKernelGGL(k_parents, dim3(blocks(n2)), dim3(256), 0, stream, (const DBvhNode*)d_bvh2, n2, parent);
+    hipLaunchKernelGGL(k_depth_owner, dim3(blocks(n2)), dim3(256), 0, stream, (const int32_t*)parent, n2, (const int32_t*)d_roots, n_roots, depth, owner);
+    BVH_TRY(hipGetLastError());
+    /* deepest level first; a tree has at most 32 inner nodes on a path (the traversal stack), the table says nothing shorter */
+    for (int level = 32; level >= 0; --level) {
+        hipLaunchKernelGGL(k_refit_level, dim3(blocks(n2)), dim3(256), 0, stream, d_bvh2, n2, (const uint8_t*)depth, (const uint8_t*)owner, (uint32_t)level,
+                           d_tris, (const float*)d_pads);
+        BVH_TRY(hipGetLastError());
+    }
+    BVH_TRY(hipStreamSynchronize(stream)); /* roots / pads / the temporaries live until here */
     return hipSuccess;
 }
 
