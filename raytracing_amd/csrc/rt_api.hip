@@ -501,13 +501,14 @@ extern "C" int rt_debug_shade_hist(unsigned long long* out65, int reset) {
  * PACK = false: one pixel per wave, lane = sample of a 64-sample chunk (spp > 32).
  * PACK = true : spp <= 32, 64 / spp pixels per wave, lane = (pixel, sample), so that few samples
  *               per pixel do not leave most lanes idle. */
-template <int M, bool PACK>
+template <int M, bool PACK, bool WORKERS>
 __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters, const uint32_t* __restrict__ order, DeepList dl, uint32_t n_workers,
                                                 uint32_t pass_spp, uint32_t pass_sample0) {
     const uint32_t lane = threadIdx.x & 63;
     __shared__ uint32_t s_stack[RT_STACK_LDS * 64 * RT_RENDER_WAVES];
-    if (blockIdx.x < n_workers) { /* the first workgroups of the launch expand the path trees of the deep list (n_workers > 0 only with RT_RENDER_WAVES == 1) */
+    /* WORKERS: the variant that holds the worker code (see RT_RENDER_CASE for which launch takes which) */
+    if (WORKERS && blockIdx.x < n_workers) { /* the first workgroups of the launch expand the path trees of the deep list (n_workers > 0 only with RT_RENDER_WAVES == 1) */
         __shared__ uint32_t s_lv[16];
         Cnt wc = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES);
 #ifdef RT_WAVE_TIMES
@@ -799,11 +800,15 @@ namespace {
         }                                                                                              \
     } while (0)
 
+/* The variants with a BVH exist with and without the worker code (measured without it, when no worker runs: 100 k-triangle
+ * frame 36.5 -> 35.1 ms, 1 M-triangle frame 1 % faster: half the register spills); the others only with it (the Cornell
+ * frame is 2 % slower without: 21.5 -> 22.0 ms, although that variant spills half as much too). */
 #define RT_RENDER_CASE(m, p, grid, stream, ...) \
-    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break;
-#define RT_DISPATCH_RENDER(mode, pack, grid, stream, ...)                                              \
+    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, ((m) & RT_M_BVH) == 0>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break; \
+    case 8 + (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, true>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break;
+#define RT_DISPATCH_RENDER(mode, pack, workers, grid, stream, ...)                                     \
     do {                                                                                               \
-        switch (((mode) & 3) * 2 + ((pack) ? 1 : 0)) {                                                 \
+        switch (((workers) ? 8 : 0) + ((mode) & 3) * 2 + ((pack) ? 1 : 0)) {                           \
             RT_RENDER_CASE(0, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(0, 1, grid, stream, __VA_ARGS__) \
             RT_RENDER_CASE(1, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(1, 1, grid, stream, __VA_ARGS__) \
             RT_RENDER_CASE(2, 0, grid, stream, __VA_ARGS__) RT_RENDER_CASE(2, 1, grid, stream, __VA_ARGS__) \
@@ -1693,7 +1698,7 @@ static int render_pass(bool static_mem, rt_scene_t scene, const rt_camera* cam, 
         const uint64_t waves = (uint64_t)rp.n_local_tiles * (((uint64_t)tile_w * tile_h + px_per_wave - 1) / px_per_wave);
         rp.spp = n; rp.sample0 = s0;
         dim3 grid((unsigned)((waves + RT_RENDER_WAVES - 1) / RT_RENDER_WAVES) + n_workers);
-        RT_DISPATCH_RENDER(r->mode, pack, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order, dl, n_workers, spp, sample0);
+        RT_DISPATCH_RENDER(r->mode, pack, n_workers > 0, grid, st, r->dev, (const DCamera*)d_cam, rp, d_rgb_tiles, d_counters, d_order, dl, n_workers, spp, sample0);
         HIP_TRY(hipGetLastError());
         s0 += n; left -= n;
         n_workers = 0;
