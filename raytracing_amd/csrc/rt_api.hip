@@ -1194,7 +1194,7 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
         (rc = upload(r, r->host.normals, &d.normals)) || (rc = upload(r, r->host.materials, &d.materials)) ||
         (rc = upload(r, r->host.lights, &d.lights)) || (rc = upload(r, r->host.kd, &d.kd)) ||
         (rc = upload(r, r->host.refs, &d.refs)) || (rc = upload(r, r->host.ref_spheres, &d.ref_spheres)) ||
-        (rc = upload(r, r->host.ref_squares, &d.ref_squares))) {
+        (rc = upload(r, r->host.ref_squares, &d.ref_squares)) || (rc = upload(r, r->host.light_sq, &d.light_sq))) {
         release(r);
         return rc;
     }

@@ -531,6 +531,20 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defe
         out.lights.push_back(o);
     }
 
+    /* which side of every square's plane the corners of every quad light lie on (DeviceScene::light_sq) */
+    for (const DLight& l : out.lights)
+        for (const DSquare& q : out.squares) {
+            const float nan = std::numeric_limits<float>::quiet_NaN();
+            float rec[4] = {nan, nan, nan, nan};
+            if (l.type == RT_LIGHT_QUAD) {
+                const float* corner[3] = {l.p0, l.p1, l.p2};
+                for (int i = 0; i < 3; ++i)
+                    rec[i] = (q.v0[0] - corner[i][0]) * q.n[0] + (q.v0[1] - corner[i][1]) * q.n[1] + (q.v0[2] - corner[i][2]) * q.n[2];
+                rec[3] = 2e-4f * len(ld(q.n));
+            }
+            out.light_sq.insert(out.light_sq.end(), rec, rec + 4);
+        }
+
     /* root box: Scene::computeGlobalAABB, R/src/Scene.h:133-166 */
     Box root;
     for (uint32_t i = 0; i < d.n_meshes; ++i)

@@ -644,7 +644,7 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
 #endif
 template <int M, int SB>
 RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&d)[SB], const float (&dist)[SB], bool (&occ)[SB], uint32_t& near,
-                         Cnt& cnt) {
+                         Cnt& cnt, uint32_t sq_mask = 0xffffffffu) {
     bool act[SB];
     cnt.rays += SB;
 #pragma unroll
@@ -699,7 +699,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
     float dist_hi[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) dist_hi[j] = dist[j] * 1.000001f;
-    for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t) {
+    auto square = [&](const DSquare& q, uint32_t) {
         f3 v0 = ld3(q.v0), n = ld3(q.n);
         float num = dot3(v0 - o, n);
         bool maybe[SB], some = false;
@@ -716,7 +716,23 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
                 float tt = num / dot3(d[j], n);
                 if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
             }
-    });
+    };
+    /* sq_mask (the same in every lane): bit q clear = no ray of this shaded point can meet square q (shade decides that
+     * once per point), and the square is not even fetched.  Scenes with more than 32 squares test them all. */
+    if (sc.n_squares > 32u || sq_mask == 0xffffffffu) for_each_record(sc.squares, sc.n_squares, square);
+    else if (sq_mask) {
+        uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)sq_mask);
+        uint32_t k = (uint32_t)__builtin_ctz(left);
+        DSquare a = ldc(&sc.squares[k]);
+        for (;;) { /* the record of the next set bit is requested before the current one is used */
+            left &= left - 1u;
+            if (!left) { square(a, k); break; }
+            const uint32_t k2 = (uint32_t)__builtin_ctz(left);
+            const DSquare b = ldc(&sc.squares[k2]);
+            square(a, k);
+            a = b; k = k2;
+        }
+    }
     for (uint32_t mi = 0; mi < sc.n_meshes; ++mi) {
         const DMesh m = ldc(&sc.meshes[mi]);
         if ((M & RT_M_BVH) && m.bvh_root >= 0) continue; /* large meshes: after everything else, see below */
@@ -1043,6 +1059,25 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
             if (!(M & RT_M_KD)) {
                 const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
                 const Rng at_first = rng; /* the stream position of light sample 0 */
+                /* Squares no shadow ray of this point can meet.  A ray runs from so to S + 0.001 N, S a mix of the light's
+                 * corners: when so and the three shifted corners lie on one side of a square's plane, each further from
+                 * it than 2e-4 (rounding moves them by 1e-6 at most), the ray crosses the plane before its origin or more
+                 * than 1e-5 of its length beyond its end, so the reference's t fails 0 <= t < |S - P| whatever its last
+                 * bits are.  Walls seen from inside the box are such squares; what remains is usually the light's own
+                 * plane and the ceiling.  A square stays if any lane of the wave needs it (NaN keeps it too). */
+                uint32_t sq_mask = 0xffffffffu;
+                if (sc.n_squares <= 32u && sc.light_sq) {
+                    sq_mask = 0u;
+                    const float* side = sc.light_sq + 4u * li * sc.n_squares;
+                    for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t k) {
+                        const f3 n = ld3(q.n);
+                        const float num = dot3(ld3(q.v0) - so, n), shift = 0.001f * dot3(N, n);
+                        const float g0 = ldc(&side[4u * k]) - shift, g1 = ldc(&side[4u * k + 1u]) - shift, g2 = ldc(&side[4u * k + 2u]) - shift;
+                        const float m = ldc(&side[4u * k + 3u]);
+                        const bool apart = (num > m && g0 > m && g1 > m && g2 > m) || (num < -m && g0 < -m && g1 < -m && g2 < -m);
+                        if (__ballot(!apart)) sq_mask |= 1u << k;
+                    });
+                }
                 uint32_t dark = 0, near = 0; /* bit i: light sample i is occluded / still has to be walked through a BVH */
                 /* With a BVH in the scene a batch whose rays are all decided (no lane of the wave has one that comes near a
                  * mesh: the usual case away from the meshes) adds its light terms right away, like the variants without a
@@ -1064,7 +1099,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
-                    shadow_batch<M, RT_SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt);
+                    shadow_batch<M, RT_SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask);
                     bool now = true; /* every ray of the batch is decided: add the light terms in sample order right away */
                     if (M & RT_M_BVH) {
                         if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;

@@ -109,6 +109,10 @@ struct DeviceScene {
     const DRef* refs;
     const DSphere* ref_spheres; /* kd-tree with internal nodes only: the record of reference r, stored at r (valid where */
     const DSquare* ref_squares; /* refs[r] names a sphere / a square): one fetch per object instead of two in a row   */
+    /* per (light l, square q), at [4 (l n_squares + q)]: dot(v0 - p_i, n) for the three corners p_i of a quad light that
+     * its samples are mixed from, and the distance from the square's plane (times |n|) below which a point counts as on
+     * it; NaN for a point light.  Decides per shaded point which squares no shadow ray of it can meet (shade). */
+    const float* light_sq;
     uint32_t n_spheres, n_squares, n_meshes, n_lights;
     uint32_t n_kd, n_refs;
     float box_lo[3], box_hi[3];  /* root box = Scene::computeGlobalAABB */
