@@ -505,7 +505,7 @@ RT_DEV void root_closest(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt, HitRec& be
         float t;
         if (square_t(rec, o, d, t) && (best.type < 0 || t < best.t)) { best.t = t; best.type = RT_SQUARE; best.obj = (int)i; }
     });
-#ifdef RT_EXP_NO_MESH_CLOSEST
+#ifdef RT_EXP_NO_MESH_CLOSEST /* attribution builds: what the meshes cost in the closest-hit queries (wrong images) */
     if (0)
 #endif
     for (uint32_t i = 0; i < sc.n_meshes; ++i) {
@@ -760,8 +760,8 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
      * for a handful of them.  The rays still undecided that reach the bounds of some mesh with a BVH are reported
      * in `near` and walked later, all light samples of the shaded point together (walk_deferred). */
     near = 0;
-#ifndef RT_EXP_NO_MESH_SHADOW
-    if (M & RT_M_BVH)
+#ifndef RT_EXP_NO_MESH_SHADOW /* attribution builds: -DRT_EXP_NO_MESH_SHADOW / _NO_WALK / _NO_MESH_CLOSEST leave a part of the */
+    if (M & RT_M_BVH)         /* mesh handling out (wrong images) to see what it costs: the numbers quoted with the pooled walks  */
 #else
     if (0)
 #endif
@@ -825,7 +825,7 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
 #ifdef RT_WALK_STATS
     const uint32_t nodes_before = cnt.bvh_nodes;
     struct Report { /* at every return: rays and lanes of the call, the longest and the summed walk (64-byte node units) */
-        uint32_t before, total, n_lanes; const Cnt& c; unsigned long long t0; uint32_t iters, refills; uint32_t last_kind; unsigned long long last_t; unsigned long long k_cycles[3]; uint32_t k_trips[3], k_lanes[3];
+        uint32_t before, total, n_lanes; const Cnt& c; unsigned long long t0; uint32_t iters, refills; uint32_t last_kind; unsigned long long last_t; unsigned long long k_cycles[3]; uint32_t k_trips[3], k_lanes[3]; unsigned long long wait_cycles; uint32_t waits;
         __device__ ~Report() {
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
             const uint32_t mine = c.bvh_nodes - before;
@@ -838,13 +838,14 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
                     atomicAdd(&rt_dbg_walk[114 + k], (unsigned long long)k_trips[k]); atomicAdd(&rt_dbg_walk[117 + k], (unsigned long long)k_lanes[k]);
                     atomicAdd(&rt_dbg_walk[120 + k], k_cycles[k]);
                 }
+                atomicAdd(&rt_dbg_walk[123], wait_cycles); atomicAdd(&rt_dbg_walk[124], (unsigned long long)waits);
                 atomicAdd(&rt_dbg_walk[5], dt); atomicAdd(&rt_dbg_walk[6], (unsigned long long)iters); atomicAdd(&rt_dbg_walk[7], (unsigned long long)refills);
                 atomicAdd(&rt_dbg_walk[8 + min(total / 8u, 39u)], 1ull);        /* rays per call, buckets of 8 */
                 atomicAdd(&rt_dbg_walk[48 + min(mx / 16u, 39u)], 1ull);         /* longest walk, buckets of 16 units */
                 atomicAdd(&rt_dbg_walk[88 + min(total / 16u, 25u)], (unsigned long long)mx); /* longest walk summed per rays bucket */
             }
         }
-    } report{nodes_before, total, n_lanes, cnt, __builtin_readcyclecounter(), 0u, 0u, 3u, 0ull, {0ull, 0ull, 0ull}, {0u, 0u, 0u}, {0u, 0u, 0u}};
+    } report{nodes_before, total, n_lanes, cnt, __builtin_readcyclecounter(), 0u, 0u, 3u, 0ull, {0ull, 0ull, 0ull}, {0u, 0u, 0u}, {0u, 0u, 0u}, 0ull, 0u};
 #endif
     auto ray = [&](uint32_t i, f3& d, float& dist) {
         f3 SP = light_sample(at_first, i, p0, p1, p2) - P;
@@ -861,11 +862,7 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
         }
         return hit;
     };
-#ifdef RT_EXP_NO_POOL
-    if (true) {
-#else
     if (longest <= 1) { /* at most one ray per lane: nothing to even out */
-#endif
         uint32_t hit = 0;
         for (uint32_t bits = near; bits; bits &= bits - 1) {
             const uint32_t i = (uint32_t)__builtin_ctz(bits);
@@ -962,7 +959,15 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
             }
         } else if (n_inner >= n_leaf) {
             if (!want && cur >= 0) { /* a wide node */
+#ifdef RT_WALK_STATS
+                const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
                 const DBvh4Node n = ldc(&sc.bvh4[cur]);
+#ifdef RT_WALK_STATS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                report.wait_cycles += __builtin_readcyclecounter() - w0; /* of the lane that reports: issue to arrival of a node */
+                ++report.waits;
+#endif
                 cnt.bvh_nodes += 2;
                 int e0, e1, e2, e3;
                 const int hits = bvh4_order(n, ro, id, rdist, e0, e1, e2, e3);
@@ -1104,9 +1109,6 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     if (M & RT_M_BVH) {
                         if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;
                         now = first_open == 16;
-#ifdef RT_EXP_ALWAYS_NOW
-                        now = true;
-#endif
 #pragma unroll
                         for (int j = 0; j < RT_SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
                         near |= near4 << i0;
@@ -1117,18 +1119,10 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                             if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
                     }
                 }
-#ifdef RT_EXP_ALWAYS_NOW
-                if ((M & RT_M_BVH) && first_open < 16) {
-                    if (__ballot(near != 0)) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
-                    if (dark == 0x12345u) sum.x += 1.f;
-                } else
-#endif
                 if ((M & RT_M_BVH) && first_open < 16) {
                     /* the undecided rays of all samples in one go, then the rest of the sum in sample order; a light direction
                      * is cheaper to rebuild from the random stream than to keep over the traversals */
-#ifdef RT_EXP_NEVER_WALK
-                    if (__ballot(near != 0) && sc.n_meshes > 1000u) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
-#elif !defined(RT_EXP_NO_WALK)
+#ifndef RT_EXP_NO_WALK /* attribution builds (see RT_EXP_NO_MESH_SHADOW): the rays near a mesh count as unoccluded */
                     if (__ballot(near != 0)) dark |= walk_deferred<M>(sc, P, so, at_first, p0, p1, p2, near, cnt);
 #endif
                     for (uint32_t i = first_open; i < 16; ++i) {

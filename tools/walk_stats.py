@@ -40,6 +40,8 @@ print(f"shader cycles inside the walk calls: {h[5]:.3e} = {h[5] / calls:.0f} per
 for k, name in enumerate(("fetch a ray", "visit a wide node", "test a leaf")):
     if h[114 + k]:
         print(f"  trips that {name:18s}: {h[114 + k] / calls:6.1f} per call, {h[117 + k] / h[114 + k]:5.1f} lanes served, {h[120 + k] / h[114 + k]:6.0f} cycles each")
+if h[124]:
+    print(f"  a wide node's fetch, issue to arrival (first lane of the wave, {int(h[124])} fetches): {h[123] / h[124]:.0f} cycles")
 print("rays per call: share of calls")
 for b in range(40):
     if h[8 + b]:
