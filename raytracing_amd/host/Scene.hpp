@@ -263,6 +263,21 @@ public:
         return device;
     }
 
+    /* The meshes moved (Mesh::translate / scale / rotate_* / a new vertex array with the same triangles, then
+     * recomputeNormals as needed) after the scene was uploaded: sends their vertices again and refits the uploaded copy
+     * (rt_scene_refit) instead of making it anew.  Returns false -- and drops the uploaded copy, so that the next query
+     * makes a new one as buildKDTree() would -- when the scene cannot be refitted (more objects than a kd leaf holds,
+     * another vertex count).  No counterpart in the reference, whose scenes do not move. */
+    bool refitMeshes() {
+        if (!device) return false;
+        std::vector<float> pos, nrm;
+        for (const Mesh& m : meshes)
+            for (const MeshVertex& v : m.vertices) for (unsigned a = 0; a < 3; ++a) { pos.push_back(v.position[a]); nrm.push_back(v.normal[a]); }
+        if (rt_scene_refit(device, pos.data(), nrm.data(), (uint32_t)(pos.size() / 3), nullptr) == RT_OK) return true;
+        drop_device();
+        return false;
+    }
+
     /* ---- batch entry points ---------------------------------------------------------------- */
     void computeIntersections(const Ray* rays, size_t n, rt_hit* out) {
         std::vector<float> org(3 * n), dir(3 * n);

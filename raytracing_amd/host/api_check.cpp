@@ -5,6 +5,7 @@
  * usage: api_check <scene 0..3> <star.off> <rays.txt>     rays.txt: "ox oy oz dx dy dz pixel sample" per line
  * output per ray: hit type object t px py pz nx ny nz | r g b | mesh: hit tIndex t [| S hit t p n] [| Q hit t p n]   (hex floats) */
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -56,6 +57,33 @@ int main(int argc, char** argv) {
                         q.normal[0], q.normal[1], q.normal[2]);
         }
         std::printf("\n");
+    }
+    /* "refit" as a fifth argument: the first mesh is moved after the scene was uploaded, Scene::refitMeshes() sends the
+     * vertices again, and every ray of the file must get the answer of a scene that was set up with the moved mesh */
+    if (argc >= 5 && std::string(argv[4]) == "refit" && !scene.getMeshes().empty()) {
+        const Vec3 by(0.25f, 0.125f, -0.0625f);
+        scene.getMeshes()[0].translate(by);
+        const bool refitted = scene.refitMeshes();
+        Scene fresh;
+        fresh.setup_cornell_box_meshes(argv[2]);
+        fresh.getMeshes()[0].translate(by);
+        fresh.buildKDTree();
+        std::ifstream again(argv[3]);
+        unsigned n = 0, differ = 0, on_mesh = 0;
+        while (std::getline(again, line)) {
+            std::istringstream ls(line);
+            float o[3], d[3];
+            if (!(ls >> o[0] >> o[1] >> o[2] >> d[0] >> d[1] >> d[2])) continue;
+            Ray ray(Vec3(o[0], o[1], o[2]), Vec3(d[0], d[1], d[2]));
+            RaySceneIntersection a = scene.computeIntersection(ray), b = fresh.computeIntersection(ray);
+            ++n;
+            if (a.intersectionExists && a.typeOfIntersectedObject == (unsigned)MESH) ++on_mesh;
+            if (a.intersectionExists != b.intersectionExists ||
+                (a.intersectionExists && (a.typeOfIntersectedObject != b.typeOfIntersectedObject || a.objectIndex != b.objectIndex ||
+                                          std::memcmp(&a.t, &b.t, sizeof(float)) != 0)))
+                ++differ;
+        }
+        std::printf("REFIT %s rays %u on_mesh %u differ %u\n", refitted ? "done" : "refused", n, on_mesh, differ);
     }
     rt_shutdown();
     return 0;

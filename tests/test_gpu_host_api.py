@@ -119,3 +119,23 @@ def test_headless_plus_and_r_keys(tmp_path):
     img, _ = o.render(orc.camera_default(w, h), w, h, spp, orc.RT_RNG_COUNTER, seed=1, threads=4)
     want = orc.quantize(img)
     assert (got != want).mean() < 1e-3 and np.abs(got.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_scene_refit_meshes_after_a_move(tmp_path):
+    """Scene::refitMeshes(): the mesh is translated after the upload; the refitted scene answers like one set up with the
+    moved mesh (api_check compares both in one process; a 1 058-triangle mesh, so a BVH is refitted)."""
+    from raytracing_amd import workloads
+    off = workloads.dome_off(24, directory=str(tmp_path))
+    org, d = rayset.primary_grid(orc, 24, 20, seed=5)
+    o2, d2 = rayset.interior_rays(1500, seed=45)
+    org, d = np.concatenate([org, o2]), np.concatenate([d, d2])
+    rays = tmp_path / "rays.txt"
+    with open(rays, "w") as f:
+        for i in range(len(org)):
+            f.write(" ".join(repr(float(x)) for x in (*org[i], *d[i])) + " 0 0\n")
+    out = subprocess.run([os.path.join(HOST_DIR, "api_check"), "3", off, str(rays), "refit"], check=True,
+                         capture_output=True, text=True, timeout=300).stdout
+    last = [ln for ln in out.splitlines() if ln.startswith("REFIT")]
+    assert len(last) == 1, out[-500:]
+    w = last[0].split()
+    assert w[1] == "done" and int(w[3]) == len(org) and int(w[5]) >= 20 and int(w[7]) == 0, last[0]

@@ -29,6 +29,8 @@ def test_device_calls_fail_loudly_without_init():
     out = np.zeros(1, api.HIT_DTYPE)
     rc = L.rt_intersect(1, z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p))
     assert rc in (-2, -4) and L.rt_last_error()
+    rc = L.rt_scene_refit(1, z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), 1, None)
+    assert rc in (-2, -4) and b"rt_scene_refit" in L.rt_last_error()
 
 
 @pytest.mark.parametrize("sid", [0, 1, 2, 3])
