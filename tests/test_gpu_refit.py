@@ -98,3 +98,27 @@ def test_refit_rejects_what_it_cannot_do():
     o = orc.Scene.from_desc(d, keep)
     assert_hits_equal(o.mesh_intersect(0, org, dr), g.mesh_intersect(0, org, dr), "refit without a BVH")
     g.close()
+
+
+@pytest.mark.parametrize("flags", [0, api.BUILD_BVH_DEVICE])
+def test_refit_of_two_meshes(flags):
+    """Two meshes with a BVH in one scene (their nodes share one table, each tree has its own pad), moved differently."""
+    m1 = scenegen.grid_mesh(20, seed=3)                                   # 722 triangles
+    m2 = scenegen.grid_mesh(14, seed=4, size=0.5, center=(0.8, 0.2, -0.5))  # 338 triangles
+    d0, keep0 = scenegen.random_objects(orc, 1, 3, 5, with_mesh=m1, second_mesh=m2)
+    g = api.DeviceScene(d0, keep=keep0, flags=flags)
+    assert g.verify()[0].bvh_meshes == 2
+    p1, n1 = _deformed(m1[0], m1[1], 21, 0.6)
+    p2, n2 = _deformed(m2[0], m2[1], 22, 0.3)
+    p2 = (p2 + np.float32([-0.4, 0.3, 0.2])).astype(np.float32)
+    g.refit(np.concatenate([p1, p2]), np.concatenate([n1, n2]))
+    g.verify()
+    d1, keep1 = scenegen.random_objects(orc, 1, 3, 5, with_mesh=(p1, n1, m1[2]), second_mesh=(p2, n2, m2[2]))
+    o1 = orc.Scene.from_desc(d1, keep1)
+    org, dr = _mesh_rays(np.concatenate([p1, p2]), 12000, seed=13)
+    for m in (0, 1):
+        want = o1.mesh_intersect(m, org, dr)
+        assert want["hit"].sum() > 500
+        assert_hits_equal(want, g.mesh_intersect(m, org, dr), f"refitted mesh {m}")
+    assert_hits_equal(o1.intersect(org, dr), g.intersect(org, dr), "refitted, two meshes")
+    g.close()
