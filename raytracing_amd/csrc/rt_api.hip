@@ -444,19 +444,25 @@ RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ c
     for (uint32_t li = 0; li < sc.n_lights; ++li) draws += ldc(&sc.lights[li].type) == RT_LIGHT_QUAD ? 32u : 0u;
     const uint32_t n_deep = min(dl.head[0], dl.cap);
     const uint64_t n_samples = (uint64_t)n_deep * spp; /* < 2^32: the list's colour table holds them */
-    /* full chunks make a worker's lanes count, small items let the workers end together: the large batch only when
-     * every worker gets several items of it (measured: 10 M-triangle share, 2.3 items of 16 per worker: 25.3 ms with
-     * 16, 26.1 ms with 32; many-spheres kd frame, 64 spp: 41.7 ms with 16, 38.8 ms with 32) */
-    const uint32_t per_item = n_samples >= 2ull * RT_TREE_BATCH * dl.n_workers ? RT_TREE_BATCH : RT_TREE_BATCH / 2;
-    const uint64_t n_items = (n_samples + per_item - 1) / per_item;
+    /* Full chunks make a worker's lanes count, small items let the workers end together.  The counter hands out units of
+     * half a batch; a worker takes two of them -- a whole batch -- while more units are left than there are workers, and
+     * single units after that, so that the last items to start are the short ones (measured with a fixed size, 10 M-triangle
+     * share, 2.3 units per worker: halves 25.3 ms, whole batches 26.1 ms; many-spheres kd frame: 41.7 / 38.8 ms). */
+    const uint32_t unit = RT_TREE_BATCH / 2;
+    const uint64_t n_units = (n_samples + unit - 1) / unit;
     uint32_t samples = 0;
-    for (;;) { /* ends for every worker: the counter only grows and n_items is fixed */
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(&dl.head[1], 1u);
-        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
-        if (item >= n_items) break;
-        const uint32_t f_end = (uint32_t)min(n_samples, ((uint64_t)item + 1) * per_item);
-        uint32_t f0 = item * per_item, batch = per_item;
+    for (;;) { /* ends for every worker: the counter only grows and n_units is fixed */
+        uint32_t first = 0, take = 1;
+        if (lane == 0) {
+            const uint32_t seen = __hip_atomic_load(&dl.head[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            take = (seen < n_units && n_units - seen > (uint64_t)dl.n_workers) ? 2u : 1u;
+            first = atomicAdd(&dl.head[1], take);
+        }
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        take = (uint32_t)__builtin_amdgcn_readfirstlane((int)take);
+        if (first >= n_units) break;
+        const uint32_t f_end = (uint32_t)min(n_samples, ((uint64_t)first + take) * unit);
+        uint32_t f0 = first * unit, batch = take * unit;
         while (f0 < f_end) {
             const uint32_t n = min(batch, f_end - f0);
             const Cnt before = cnt; /* a batch that does not fit is traced again in halves: its counts are dropped */
