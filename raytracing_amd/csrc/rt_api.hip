@@ -105,6 +105,17 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4 /* waves per SIMD the render variants are compiled for (<= 128 VGPRs) */
 #endif
+/* The variant of the scenes whose objects all sit in one leaf and that have no BVH (mode 0: every built-in scene) waits
+ * for its own instructions more than it computes, so it runs best with more, smaller waves: shadow rays in batches of
+ * two instead of four (RT_SB0) fit 80 VGPRs, i.e. six waves per SIMD, with three LDS levels of path frames
+ * (3 x 7 x 256 B x 24 waves = 126 KB of the CU's 160 KB).  Measured on the Cornell 1080p frame, batch / waves:
+ * 4 / 4 21.6 ms, 2 / 4 22.6, 4 / 5 22.7, 2 / 5 21.2, 2 / 6 20.45, 2 / 7 20.6, 2 / 8 21.3, 1 / 6 21.8, 1 / 8 22.6. */
+#ifndef RT_MIN_WAVES0
+#define RT_MIN_WAVES0 6
+#endif
+#ifndef RT_FRAME_LDS0
+#define RT_FRAME_LDS0 3
+#endif
 #ifdef RT_WAVES_PER_EU
 #define RT_OCC __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #else
@@ -508,7 +519,7 @@ extern "C" int rt_debug_shade_hist(unsigned long long* out65, int reset) {
  * PACK = true : spp <= 32, 64 / spp pixels per wave, lane = (pixel, sample), so that few samples
  *               per pixel do not leave most lanes idle. */
 template <int M, bool PACK, bool WORKERS>
-__global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
+__global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_MIN_WAVES)) RT_OCC void k_render(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, float* __restrict__ out,
                                                 uint64_t* __restrict__ counters, const uint32_t* __restrict__ order, DeepList dl, uint32_t n_workers,
                                                 uint32_t pass_spp, uint32_t pass_sample0) {
     const uint32_t lane = threadIdx.x & 63;
@@ -555,7 +566,8 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
     /* path frames: the first L levels in LDS.  A variant without a BVH never touches s_stack (the compiler drops it), so at
      * 4 waves / SIMD = 16 waves per CU each wave can have 10 KB of the CU's 160 KB; the variants that traverse a BVH
      * need their LDS for the traversal stack and keep the frames in the per-lane array */
-    constexpr int L = (M & RT_M_BVH) ? 0 : RT_FRAME_LDS;
+    constexpr int L = (M & RT_M_BVH) ? 0 : (M == 0 ? RT_FRAME_LDS0 : RT_FRAME_LDS);
+    constexpr int SB = M == 0 ? RT_SB0 : RT_SB;
     __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 64 * RT_RENDER_WAVES : 1];
     Cnt cnt = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES, s_frames + (L ? threadIdx.x : 0), 64 * RT_RENDER_WAVES);
     uint32_t my_samples = 0;
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
             primary_ray(*cam, u, v, o, d);
-            col = trace_path<M, false, L>(sc, o, norm3_unit(d), rng, cnt);
+            col = trace_path<M, false, L, SB>(sc, o, norm3_unit(d), rng, cnt);
             ++my_samples;
         }
         for (uint32_t i = 0; i < rp.spp; ++i) { /* every lane of the wave takes part in the shuffles */
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, RT_MIN_WAVES) RT_OCC void k_r
                 float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
                 f3 o, d;
                 primary_ray(*cam, u, v, o, d);
-                col = trace_path<M, false, L>(sc, o, norm3_unit(d), rng, cnt); /* Ray(pos, dir) normalises again */
+                col = trace_path<M, false, L, SB>(sc, o, norm3_unit(d), rng, cnt); /* Ray(pos, dir) normalises again */
                 ++my_samples;
             }
             /* image[x + y*w] += color, one sample after the other */
@@ -806,11 +818,11 @@ namespace {
         }                                                                                              \
     } while (0)
 
-/* The variants with a BVH exist with and without the worker code (measured without it, when no worker runs: 100 k-triangle
- * frame 36.5 -> 35.1 ms, 1 M-triangle frame 1 % faster: half the register spills); the others only with it (the Cornell
- * frame is 2 % slower without: 21.5 -> 22.0 ms, although that variant spills half as much too). */
+/* Every variant but the one for kd-trees with internal nodes exists with and without the worker code, and a launch
+ * without workers takes the one without (measured: 100 k-triangle frame 36.5 -> 35.1 ms, 1 M-triangle frame 1 % faster,
+ * the Cornell frame unchanged at 20.6 ms -- but 384 instead of 544 bytes of scratch per lane and a third of the spills). */
 #define RT_RENDER_CASE(m, p, grid, stream, ...) \
-    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, ((m) & RT_M_BVH) == 0>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break; \
+    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, (m) == 1>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break; \
     case 8 + (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, true>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break;
 #define RT_DISPATCH_RENDER(mode, pack, workers, grid, stream, ...)                                     \
     do {                                                                                               \

@@ -640,7 +640,10 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
  * Every value is still produced by the reference's operations in the reference's order; the
  * answer per ray is "the closest hit exists and its t < dist", i.e. some object reports t < dist. */
 #ifndef RT_SB
-#define RT_SB 4
+#define RT_SB 4 /* rays per batch; the render variant of scenes without kd nodes or BVH takes RT_SB0 (see k_render) */
+#endif
+#ifndef RT_SB0
+#define RT_SB0 2
 #endif
 template <int M, int SB>
 RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&d)[SB], const float (&dist)[SB], bool (&occ)[SB], uint32_t& near,
@@ -1040,8 +1043,9 @@ RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
 __device__ unsigned long long rt_dbg_hist[65];
 #endif
 /* ---- Scene::phong, R/src/Scene.h:319-422 (+ samplePointOnLight :252-276) ------------------ */
-template <int M>
+template <int M, int SB = RT_SB>
 RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
+    static_assert(16 % SB == 0, "the 16 light samples of a quad light come in whole batches");
     ++cnt.nodes;
 #ifdef RT_SHADE_HIST
     { /* the predicate depends on per-lane data so that the ballot cannot be moved out of the (divergent) path loop */
@@ -1089,13 +1093,13 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                  * BVH.  From the first batch that leaves a ray open the terms wait -- the sum runs in sample order -- and
                  * are added after the walks, their light directions rebuilt from the random stream. */
                 uint32_t first_open = 16; /* wave-uniform: the first sample whose light term is still to be added */
-                for (int i0 = 0; i0 < 16; i0 += RT_SB) {
-                    f3 L[RT_SB], Ld[RT_SB];
-                    float dist[RT_SB];
-                    bool occ[RT_SB];
+                for (int i0 = 0; i0 < 16; i0 += SB) {
+                    f3 L[SB], Ld[SB];
+                    float dist[SB];
+                    bool occ[SB];
                     uint32_t near4;
 #pragma unroll
-                    for (int j = 0; j < RT_SB; ++j) {
+                    for (int j = 0; j < SB; ++j) {
                         float u = rng.unit();
                         float v = rng.unit();
                         if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
@@ -1104,18 +1108,18 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
-                    shadow_batch<M, RT_SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask);
+                    shadow_batch<M, SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask);
                     bool now = true; /* every ray of the batch is decided: add the light terms in sample order right away */
                     if (M & RT_M_BVH) {
                         if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;
                         now = first_open == 16;
 #pragma unroll
-                        for (int j = 0; j < RT_SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
+                        for (int j = 0; j < SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
                         near |= near4 << i0;
                     }
                     if (now) {
 #pragma unroll
-                        for (int j = 0; j < RT_SB; ++j)
+                        for (int j = 0; j < SB; ++j)
                             if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
                     }
                 }
@@ -1253,7 +1257,7 @@ struct FrameStack {
         }
     }
 };
-template <int M, bool PROBE = false, int L = 0>
+template <int M, bool PROBE = false, int L = 0, int SB = RT_SB>
 RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
     FrameStack<L> stk;
     stk.lds = (rt_lds_f32*)cnt.frames; stk.stride = cnt.frame_stride;
@@ -1275,7 +1279,7 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
             if (bounces) { mat = ldc(&sc.spheres[h.obj].mat); mtype = ldc(&sc.materials[mat].type); }
             if (PROBE) { if (++cnt.nodes >= RT_PROBE_CAP) return ret; }
             else if (mtype == RT_MAT_GLASS) skip_shade(sc, rng, cnt);
-            else col = shade<M>(sc, h, rng, cnt);
+            else col = shade<M, SB>(sc, h, rng, cnt);
             ret = col;
             if (bounces && mtype != RT_MAT_DIFFUSE) {
                 const Bounce bn = bounce_rays(sc, mtype, mat, h.p, h.n, d);
