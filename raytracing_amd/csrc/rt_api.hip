@@ -719,7 +719,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_KTRACE_W
                                                const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
-    /* as in k_render: 4 waves per SIMD, and the first levels of the path-frame stack in LDS where no BVH stack needs it */
+    /* 4 waves per SIMD and batches of four in every variant (lane = ray: six waves with batches of two, which pay in k_render's
+     * variant 0, make the Cornell batch 4 % slower here), the first levels of the path-frame stack in LDS where no BVH stack
+     * needs it */
     constexpr int L = (M & RT_M_BVH) ? 0 : RT_FRAME_LDS;
     __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 256 : 1];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
