@@ -639,6 +639,14 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
  * once per batch, and the independent dependency chains give the scheduler work to interleave.
  * Every value is still produced by the reference's operations in the reference's order; the
  * answer per ray is "the closest hit exists and its t < dist", i.e. some object reports t < dist. */
+/* The constant term of Sphere::intersect's quadratic, R/src/Sphere.h: (o - c).norm() * (o - c).norm() - r * r (square root,
+ * then square).  All shadow rays of a shaded point share their origin, so shade computes it once per point for the first
+ * RT_SPH_KEPT spheres instead of once per batch. */
+#define RT_SPH_KEPT 2
+RT_DEV float sphere_c(const DSphere& s, f3 o) {
+    const float n = len3(o - ld3(s.c));
+    return (n * n) - s.r2;
+}
 #ifndef RT_SB
 #define RT_SB 4 /* rays per batch; the render variant of scenes without kd nodes or BVH takes RT_SB0 (see k_render) */
 #endif
@@ -647,7 +655,7 @@ RT_DEV bool occluded(const DeviceScene& sc, f3 o, f3 d, float dist, Cnt& cnt) {
 #endif
 template <int M, int SB>
 RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&d)[SB], const float (&dist)[SB], bool (&occ)[SB], uint32_t& near,
-                         Cnt& cnt, uint32_t sq_mask = 0xffffffffu) {
+                         Cnt& cnt, uint32_t sq_mask, const float (&sph_c)[RT_SPH_KEPT]) {
     bool act[SB];
     cnt.rays += SB;
 #pragma unroll
@@ -662,10 +670,14 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
     /* tables walked directly with one-ahead record fetches, as in root_closest */
     /* Per object the cheap part runs for all rays of the batch first, in straight-line code, and the rare
      * expensive part sits behind ONE wave-level branch per object instead of one per ray. */
-    for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& s, uint32_t) {
+    for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& s, uint32_t si) {
         f3 oc = o - ld3(s.c);
-        float n = len3(oc);
-        float c = (n * n) - s.r2;
+        float c; /* |o - c|^2 - r^2 depends on the origin only: the caller computed it for the first spheres (sphere_c) */
+        if (si < RT_SPH_KEPT) {
+            c = sph_c[0];
+#pragma unroll
+            for (uint32_t k = 1; k < RT_SPH_KEPT; ++k) c = si == k ? sph_c[k] : c;
+        } else c = sphere_c(s, o);
         float b[SB], delta[SB];
         bool some = false;
 #pragma unroll
@@ -1087,6 +1099,9 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         if (__ballot(!apart)) sq_mask |= 1u << k;
                     });
                 }
+                float sph_c[RT_SPH_KEPT];
+#pragma unroll
+                for (uint32_t k = 0; k < RT_SPH_KEPT; ++k) sph_c[k] = k < sc.n_spheres ? sphere_c(ldc(&sc.spheres[k]), so) : 0.f;
                 uint32_t dark = 0, near = 0; /* bit i: light sample i is occluded / still has to be walked through a BVH */
                 /* With a BVH in the scene a batch whose rays are all decided (no lane of the wave has one that comes near a
                  * mesh: the usual case away from the meshes) adds its light terms right away, like the variants without a
@@ -1108,7 +1123,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
                     }
-                    shadow_batch<M, SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask);
+                    shadow_batch<M, SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask, sph_c);
                     bool now = true; /* every ray of the batch is decided: add the light terms in sample order right away */
                     if (M & RT_M_BVH) {
                         if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;
