@@ -607,11 +607,19 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
             }
             /* image[x + y*w] += color, one sample after the other */
             const uint32_t n = min(64u, rp.spp - s0);
-            for (uint32_t i = 0; i < n; ++i) {
-                acc.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.x), (int)i));
-                acc.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.y), (int)i));
-                acc.z += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.z), (int)i));
-            }
+            if (n == 64u) { /* a full chunk: straight-line code, no branch per sample */
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    acc.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.x), i));
+                    acc.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.y), i));
+                    acc.z += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.z), i));
+                }
+            } else
+                for (uint32_t i = 0; i < n; ++i) {
+                    acc.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.x), (int)i));
+                    acc.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.y), (int)i));
+                    acc.z += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col.z), (int)i));
+                }
         }
     }
     if (rp.sample0 + rp.spp == rp.spp_total) acc = acc / (float)rp.spp_total; /* image /= nsamples */

@@ -1038,10 +1038,13 @@ RT_DEV float pow_shiny(float x, float y) {
 }
 
 /* Scene::computeLightContribution, R/src/Scene.h:304-316 */
-RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V, f3 L) {
+/* all16 (the same in every lane): every lane's material has shininess 16, so the exponent needs no per-lane branches */
+RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V, f3 L, bool all16 = false) {
     f3 R = norm3_unit((2.f * dot3(N, L)) * N - L);
     float nl = max_std(0.f, dot3(L, N));
-    float sp = pow_shiny(max_std(0.f, dot3(R, V)), m.shininess);
+    float sp;
+    if (all16) sp = pow_shiny(max_std(0.f, dot3(R, V)), 16.0f);
+    else sp = pow_shiny(max_std(0.f, dot3(R, V)), m.shininess);
     sum.x += lt.color[0] * m.kd[0] * nl; sum.x += lt.color[0] * m.ks[0] * sp;
     sum.y += lt.color[1] * m.kd[1] * nl; sum.y += lt.color[1] * m.ks[1] * sp;
     sum.z += lt.color[2] * m.kd[2] * nl; sum.z += lt.color[2] * m.ks[2] * sp;
@@ -1072,6 +1075,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     const f3 N = norm3_unit(h.n);
     const f3 V = norm3(-1.f * P);              /* camera assumed at the world origin */
     const f3 so = P + 0.001f * N;              /* shadow-ray origin */
+    const bool all16 = __ballot(m.shininess != 16.0f) == 0ull; /* decided once per shaded point for the whole wave */
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const DLight lt = ldc(&sc.lights[li]);
         if (lt.type == RT_LIGHT_QUAD) {
@@ -1135,7 +1139,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     if (now) {
 #pragma unroll
                         for (int j = 0; j < SB; ++j)
-                            if (!occ[j]) light_term(sum, lt, m, N, V, L[j]);
+                            if (!occ[j]) light_term(sum, lt, m, N, V, L[j], all16);
                     }
                 }
                 if ((M & RT_M_BVH) && first_open < 16) {
