@@ -69,12 +69,39 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+/* The same sum, in a wave-uniform register, by data-parallel-primitive adds (an inclusive scan within each row of 16 lanes,
+ * then the row totals carried into the next rows: lane 63 ends up with the total): six VALU instructions where the
+ * shuffles above are six round trips through the LDS crossbar. */
+RT_DEV uint32_t wave_total(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); /* row_shr:1, lanes without a source add 0 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); /* row_shr:8 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
 /* one set of atomics per workgroup, into the workgroup's slot (see RT_COUNTER_SLOTS): a single
- * shared address would serialise ~6 M atomics per frame at ~12 ns each */
-template <int M>
+ * shared address would serialise ~6 M atomics per frame at ~12 ns each.  ONE_WAVE: the workgroup is a single wave whose
+ * lanes are all here (k_render): no LDS partial sums and no barriers, lane k adds field k. */
+template <int M, bool ONE_WAVE = false>
 RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     if (!counters) return;
     constexpr int N = RT_COUNTER_FIELDS;
+    if (ONE_WAVE) {
+        uint32_t t[N] = {wave_total(c.rays), wave_total(samples), wave_total(c.nodes), 0u, 0u, wave_total(c.skipped)};
+        if (M & RT_M_BVH) { t[3] = wave_total(c.bvh_nodes); t[4] = wave_total(c.bvh_tris); }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) mine = (int)threadIdx.x == k ? t[k] : mine;
+        if (threadIdx.x < N && mine) {
+            uint64_t* slot = counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_STRIDE;
+            atomicAdd((unsigned long long*)&slot[threadIdx.x], (unsigned long long)mine);
+        }
+        return;
+    }
     __shared__ uint32_t part[N];
     if (threadIdx.x < N) part[threadIdx.x] = 0;
     __syncthreads();
@@ -539,7 +566,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
             rt_dbg_times[at + 2] = (0xfffffull << 44) | ((unsigned long long)min(done, 0xfffffu) << 24);
         }
 #endif
-        flush_counters<M>(counters, wc, done);
+        flush_counters<M, RT_RENDER_WAVES == 1>(counters, wc, done);
         return;
     }
     const uint8_t* __restrict__ deep_flags = dl.flags;
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
         }
     }
 #endif
-    flush_counters<M>(counters, cnt, my_samples); /* every thread of the workgroup reaches this barrier */
+    flush_counters<M, RT_RENDER_WAVES == 1>(counters, cnt, my_samples); /* every thread of the workgroup reaches this point */
 }
 /* image[x + y*w] += colour, sample after sample (R/main.cpp:191), for the pixels of the deep list; the pass that
  * reaches spp_total divides (R/main.cpp:193) -- what k_render does for the other pixels.  One thread per pixel. */
