@@ -570,7 +570,9 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
         return;
     }
     const uint8_t* __restrict__ deep_flags = dl.flags;
-    const uint32_t wave = (blockIdx.x - n_workers) * (uint32_t)RT_RENDER_WAVES + (threadIdx.x >> 6);
+    /* a single-wave workgroup: the wave number, and with it the tile, the pixel and the output address of an unpacked wave,
+     * depend on the workgroup id alone, which lets the compiler keep them in scalar registers */
+    const uint32_t wave = (blockIdx.x - n_workers) * (uint32_t)RT_RENDER_WAVES + (RT_RENDER_WAVES == 1 ? 0u : threadIdx.x >> 6);
     const uint32_t px_per_tile = rp.tile_w * rp.tile_h;
     const uint32_t px_per_wave = PACK ? 64u / rp.spp : 1u;
     const uint32_t waves_per_tile = PACK ? (px_per_tile + px_per_wave - 1) / px_per_wave : px_per_tile;
@@ -598,8 +600,8 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
     __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 64 * RT_RENDER_WAVES : 1];
     Cnt cnt = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES, s_frames + (L ? threadIdx.x : 0), 64 * RT_RENDER_WAVES);
     uint32_t my_samples = 0;
-    f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane of a pixel */
-    if (in_image && rp.sample0 > 0) acc = ld3(dst);
+    f3 acc = mk3(0.f, 0.f, 0.f); /* identical in every lane of a pixel; the sum a later pass continues is fetched where the
+                                  * additions start, not here: it would occupy three registers while the paths are traced */
     if (PACK) {
         const uint32_t first_lane = sub * rp.spp, s = rp.sample0 + (lane - first_lane);
         f3 col = mk3(0.f, 0.f, 0.f);
@@ -612,6 +614,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
             col = trace_path<M, false, L, SB>(sc, o, norm3_unit(d), rng, cnt);
             ++my_samples;
         }
+        if (in_image && rp.sample0 > 0) acc = ld3(dst);
         for (uint32_t i = 0; i < rp.spp; ++i) { /* every lane of the wave takes part in the shuffles */
             const int src = (int)(min(first_lane, 63u) + i) & 63;
             acc.x += __shfl(col.x, src, 64);
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
                 ++my_samples;
             }
             /* image[x + y*w] += color, one sample after the other */
+            if (s0 == 0 && rp.sample0 > 0) acc = ld3(dst);
             const uint32_t n = min(64u, rp.spp - s0);
             if (n == 64u) { /* a full chunk: straight-line code, no branch per sample */
 #pragma unroll
