@@ -12,11 +12,16 @@ closest-hit query traced (primary, shadow, reflected, refracted) of all ranks pe
 
 The same JSON line carries
   roofline      c1 / c2 (7 objects, the scene lives in the scalar cache): the render kernel against the FP32 vector
-                peak: algorithmic FLOP per launch (reference-equivalent rays per launch x FLOP per ray, the latter
-                counted by the CPU oracle with the constants of include/rt_flops.h) / the kernel's mean duration
-                (HIP events on the launch stream).  c3 .. c5 (triangle BVH): against the HBM peak: algorithmic bytes
-                per launch (64 B per BVH node fetched + 48 B per triangle tested, both counted by the kernel, + 32 B
-                per ray + 12 B per sample) / the same duration.
+                peak.  `frac` counts the work of the rays the kernel traces: rays traced per launch x algorithmic FLOP per
+                traced ray (counted by the CPU oracle with the constants of include/rt_flops.h, the Phong evaluations whose
+                colour the reference overwrites left out) / the kernel's mean duration (HIP events on the launch stream);
+                `frac_reference_work` counts everything the reference executes, discarded work included.  The reference
+                arithmetic has no fused multiply-add, so 0.5 of the peak is the ceiling (`ceiling_no_fma`).
+                c3 .. c5 (triangle BVH): what the hardware counters of the same kernel sources say (profiles/counters_cX.json,
+                rocprofv3 --pmc, reported only while the kernel sources are unchanged): memory-side bytes per launch / the
+                live kernel duration against the HBM peak, L2 request rate and hit rate, VALU issue share and active lanes;
+                the logical bytes (64 B per BVH node fetched + 48 B per triangle tested + 32 B per ray + 12 B per sample)
+                are given as `algorithmic_bytes`, not as a fraction of anything.
   cpu_baseline  the CPU oracle (a port of the reference algorithm, one thread like the reference)
                 timed on this host on a bounded sample of the same workload (N = 1 only)
 Launch: python bench.py [--gpus N --steps K --warmup W --config cX]; for N > 1 through torch.distributed.run.
@@ -33,38 +38,53 @@ if ROOT not in sys.path:
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X spec: 256 CU x 4 SIMD x 16 lanes x 2 (packed) x 2 (FMA) x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
-# Memory-side traffic per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, bytes) of the default spp of each workload, measured
-# offline with tools/pmc_traffic.sh / tools/pmc_config.sh on the build whose kernels have the hash below; the counters
-# cannot be read from inside the process, so the figure is reported only while the kernel sources are unchanged.
-PROFILED_TRAFFIC = {}
+# Hardware counters (memory-side traffic, L2, SQ) cannot be read from inside the process: they are measured offline with
+# tools/prof_round3.sh on the default frame of each workload and kept in profiles/counters_<config>.json with the hash of the
+# kernel sources; the line reports them only while that hash still matches.
 
 
 def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
-    for f in ("rt_device.h", "rt_api.hip", "rt_types.h"):
+    for f in ("rt_device.h", "rt_kernels.h", "rt_types.h"):
         with open(os.path.join(ROOT, "raytracing_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read().split(b"host state")[0])  # rt_api.hip: the kernels come first, host code after that banner
+            h.update(fh.read())
     return h.hexdigest()[:12]
 
 
-def profiled_traffic(config, world):
-    """(bytes per launch, note) from profiles/traffic_<config>.json if it was measured on the current kernel sources."""
-    path = os.path.join(ROOT, "profiles", f"traffic_{config}.json")
+def profiled_counters(config, world):
+    """(record, note): profiles/counters_<config>.json (tools/counters_json.py: rocprofv3 --pmc passes of one frame) if it
+    was measured on the current kernel sources, else (None, why not)."""
+    path = os.path.join(ROOT, "profiles", f"counters_{config}.json")
     if world != 1 or not os.path.exists(path):
         return None, "not measured for this configuration / rank count"
     with open(path) as fh:
         rec = json.load(fh)
     if rec.get("kernel_source_hash") != kernel_source_hash():
         return None, f"{os.path.relpath(path, ROOT)} was measured on other kernel sources ({rec.get('kernel_source_hash')}); not reported"
-    return rec["fetch_bytes"] + rec["write_bytes"], (f"profiled offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, {os.path.relpath(path, ROOT)} "
-                                                     f"(fetch {rec['fetch_bytes'] / 1e9:.3f} GB, write {rec['write_bytes'] / 1e9:.3f} GB; memory-side requests of the L2, "
-                                                     "Infinity-Cache hits included)")
+    return rec, (f"profiled offline: one rocprofv3 --pmc run per counter set over one frame, {os.path.relpath(path, ROOT)}; FETCH_SIZE / WRITE_SIZE are "
+                 "memory-side requests of the L2 (Infinity-Cache hits included); fetch_bytes_x2 applies the gfx950 rule that a 128-B read request is "
+                 "tallied as 64 B, an upper bound for the dword-per-lane scratch reloads that dominate here")
+
+
+def counter_fields(rec, kernel_s):
+    """The counter-derived figures of one launch, rates taken with the live kernel duration."""
+    if rec is None:
+        return {}
+    out = {"fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"], "fetch_bytes_x2": 2 * rec["fetch_bytes"],
+           "fabric_gbs": round((2 * rec["fetch_bytes"] + rec["write_bytes"]) / kernel_s / 1e9, 1)}
+    if "TCC_REQ_sum" in rec:
+        out["l2_request_gbs"] = round(rec["TCC_REQ_sum"] * 128 / kernel_s / 1e9, 1)
+    for k in ("l2_hit_rate", "valu_issue_share", "active_lanes", "wait_inst_any_share", "wait_any_share", "valu_insts_per_64_traced_rays", "profiled_frame_ms"):
+        if k in rec:
+            out[k] = rec[k]
+    return out
 
 
 def cpu_baseline(w, h, spp, seed, threads=1):
     """Oracle render of the same frame at reduced spp on the host cores; returns the record for the
-    JSON line and the algorithmic FLOP per ray of the workload."""
+    JSON line and the algorithmic FLOP per ray of the workload: over everything the reference executes, and over the rays
+    that remain when the Phong evaluations it discards (glass nodes) are left out."""
     from oracle import orc
     scene = orc.Scene.builtin(2)
     cam = orc.camera_default(w, h)
@@ -73,6 +93,7 @@ def cpu_baseline(w, h, spp, seed, threads=1):
     _, st = scene.render(cam, w, h, spp, orc.RT_RNG_COUNTER, seed, threads=threads)
     dt = time.perf_counter() - t0
     counters, flops = scene.counters()
+    dead_rays, dead_flops = scene.discarded_work()
     rec = {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"same scene and camera, {w}x{h} at {spp} spp ({st.samples} samples, {st.rays} rays, {dt:.1f} s)",
            "rays_per_sample": round(st.rays / st.samples, 3)}
@@ -83,7 +104,7 @@ def cpu_baseline(w, h, spp, seed, threads=1):
         _, st2 = scene.render(cam, w, h, spp, orc.RT_RNG_COUNTER, seed, threads=many)
         dt2 = time.perf_counter() - t0
         rec["all_cores"] = {"value": round(st2.rays / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": many, "seconds": round(dt2, 2)}
-    return rec, flops / st.rays
+    return rec, flops / st.rays, (flops - dead_flops) / (st.rays - dead_rays)
 
 
 def cpu_baseline_mesh(wl, seed):
@@ -124,7 +145,8 @@ def main():
     ap.add_argument("--tile", type=int, default=8, help="tile edge in pixels (8: the shares of 8 ranks differ by 2 % on the Cornell frame, 16: by 4 %)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=3, help="spp of the bounded CPU-baseline sample of c1 / c2 (0 = skip the CPU baseline)")
-    ap.add_argument("--flop-per-ray", type=float, default=0.0, help="override instead of counting on the CPU")
+    ap.add_argument("--flop-per-ray", type=float, default=0.0, help="override instead of counting on the CPU (over all reference rays)")
+    ap.add_argument("--flop-per-traced-ray", type=float, default=0.0, help="the same over the rays traced (discarded Phong evaluations left out)")
     ap.add_argument("--native-gather", action="store_true", help="N > 1: exchange the tiles with the library's own RCCL calls (rt_gather_tiles_device)")
     args = ap.parse_args()
 
@@ -233,41 +255,58 @@ def main():
         dt_max, kernel_ms_max = dt, kernel_ms
     # rays_total counts what the reference does: one per Scene::computeIntersection call.  The shadow queries of glass nodes,
     # whose Phong colour the reference computes and then overwrites, are counted there but not traced: `value` is on the
-    # rays actually traced, the FP32 roofline numerator (algorithmic work) on the reference's count.
+    # rays actually traced, and so is `roofline.frac`; `roofline.frac_reference_work` uses the reference's count.
     traced_total = rays_total - skipped_total
 
     if rank == 0:
         img = image
         assert torch.isfinite(img).all() and float(img.mean()) > 0.01, "render produced an empty / non-finite image"
-        cpu_rec, flop_per_ray = None, args.flop_per_ray
+        cpu_rec, flop_per_ray, flop_per_traced = None, args.flop_per_ray, args.flop_per_traced_ray
         if world == 1 and args.cpu_spp > 0:
             if mesh:
                 cpu_rec = cpu_baseline_mesh(wl, args.seed)
             else:
-                cpu_rec, counted = cpu_baseline(w, h, args.cpu_spp, args.seed)
+                cpu_rec, counted, counted_traced = cpu_baseline(w, h, args.cpu_spp, args.seed)
                 if flop_per_ray <= 0:
                     flop_per_ray = counted
+                if flop_per_traced <= 0:
+                    flop_per_traced = counted_traced
         if flop_per_ray <= 0:
-            flop_per_ray = 488.97  # what the oracle counts on the c2 frame (include/rt_flops.h constants)
-        traffic, traffic_note = profiled_traffic(args.config, world) if (w, h, spp) == (wl.w, wl.h, wl.spp) else (None, "non-default frame")
+            flop_per_ray = 488.97      # what the oracle counts on the c2 frame (include/rt_flops.h constants): per reference ray,
+        if flop_per_traced <= 0:
+            flop_per_traced = 479.43   # and per ray that is left when the discarded Phong evaluations of glass nodes are taken out
+        counters_rec, counters_note = profiled_counters(args.config, world) if (w, h, spp) == (wl.w, wl.h, wl.spp) else (None, "non-default frame")
         per_launch = 1.0 / steps / world            # this rank's launches ~ 1 / world of the frame
+        kernel_s = kernel_ms_max * 1e-3
+        cf = counter_fields(counters_rec, kernel_s)
+        traffic = (counters_rec["fetch_bytes"] + counters_rec["write_bytes"]) if counters_rec else None
+        common = {"traffic": traffic, "traffic_note": counters_note, "counters": cf or None, "kernel": "k_render", "kernel_ms": round(kernel_ms_max, 3),
+                  "kernel_mrays_per_s": round(traced_total * per_launch / kernel_s / 1e6, 2)}
         if mesh:
+            # What bounds these kernels is read from the counters, not assumed: the walks are chains of dependent node fetches
+            # (most of them L2 hits) in divergent code, far from the HBM rate.  Without counters of this build only the logical
+            # bytes are known, and they are not a measure of memory traffic (32 B per ray + 12 B per sample never leave the
+            # registers of a fused kernel), so no fraction is derived from them.
             alg_bytes = (bvh_nodes * 64 + bvh_tris * 48 + traced_total * 32 + samples_total * 12) * per_launch
-            achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                        "kernel": "k_render", "kernel_ms": round(kernel_ms_max, 3),
+            fabric = cf.get("fabric_gbs")
+            roofline = {"bound": "latency+divergent_valu" if cf else "unclassified (no hardware counters of this build)",
+                        "achieved": fabric, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fabric / HBM_PEAK_GBS, 4) if fabric else None,
+                        "achieved_is": "memory-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of the profiled frame) / live kernel duration",
+                        "algorithmic_bytes": int(alg_bytes), "algorithmic_gbs": round(alg_bytes / kernel_s / 1e9, 1),
+                        "algorithmic_bytes_are": "64 B per BVH node fetched + 48 B per triangle tested (kernel counters) + 32 B per ray + 12 B per sample",
                         "bytes_per_ray": round(alg_bytes / (traced_total * per_launch), 1),
-                        "bvh_nodes_per_ray": round(bvh_nodes / traced_total, 3), "bvh_tris_per_ray": round(bvh_tris / traced_total, 3),
-                        "numerator": "64 B per BVH node fetched + 48 B per triangle tested (kernel counters) + 32 B per ray + 12 B per sample",
-                        "kernel_mrays_per_s": round(traced_total * per_launch / (kernel_ms_max * 1e-3) / 1e6, 2)}
+                        "bvh_nodes_per_ray": round(bvh_nodes / traced_total, 3), "bvh_tris_per_ray": round(bvh_tris / traced_total, 3)}
         else:
-            achieved = rays_total * per_launch * flop_per_ray / (kernel_ms_max * 1e-3) / 1e12
+            achieved = traced_total * per_launch * flop_per_traced / kernel_s / 1e12
+            achieved_ref = rays_total * per_launch * flop_per_ray / kernel_s / 1e12
             roofline = {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                        "kernel": "k_render", "kernel_ms": round(kernel_ms_max, 3), "flop_per_ray": round(flop_per_ray, 2),
-                        "numerator": "reference-equivalent rays per launch x FLOP per ray (both counted by the CPU oracle's rules)",
-                        "kernel_mrays_per_s": round(traced_total * per_launch / (kernel_ms_max * 1e-3) / 1e6, 2)}
+                        "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "ceiling_no_fma": 0.5,
+                        "numerator": "rays traced per launch x algorithmic FLOP per traced ray (CPU oracle's count, discarded Phong evaluations excluded; "
+                                     "an upper bound of the arithmetic executed: any-hit shadow tests and culled squares do less than the reference's loops)",
+                        "flop_per_traced_ray": round(flop_per_traced, 2),
+                        "achieved_reference_work": round(achieved_ref, 3), "frac_reference_work": round(achieved_ref / FP32_VECTOR_PEAK_TFLOPS, 4),
+                        "flop_per_reference_ray": round(flop_per_ray, 2)}
+        roofline.update(common)
         names = {"c1": "Cornell 480x480 50spp", "c2": "Cornell 1080p 64spp", "c3": "100k-triangle mesh scene 1080p 64spp",
                  "c4": "1M-triangle mesh scene 4K 256spp", "c5": "10M-triangle scene 1080p 64spp progressive"}
         line = {

@@ -113,6 +113,8 @@ def lib():
         L.orc_scene_counters.restype = C.c_double
         L.orc_scene_counters.argtypes = [vp, vp]
         L.orc_scene_counters_reset.argtypes = [vp]
+        L.orc_scene_discarded_work.restype = C.c_double
+        L.orc_scene_discarded_work.argtypes = [vp, vp]
         L.orc_selfcheck.restype = C.c_int
         _lib = L
     return _lib
@@ -219,6 +221,12 @@ class Scene:
         out = np.zeros(16, np.uint64)
         flops = lib().orc_scene_counters(self.h, _ptr(out))
         return dict(zip(COUNTER_NAMES, (int(v) for v in out))), flops
+
+    def discarded_work(self):
+        """(closest-hit queries, algorithmic FLOP) the reference spends on Phong colours it overwrites (glass nodes)."""
+        rays = np.zeros(1, np.uint64)
+        flops = lib().orc_scene_discarded_work(self.h, _ptr(rays))
+        return int(rays[0]), flops
 
     def reset_counters(self):
         lib().orc_scene_counters_reset(self.h)

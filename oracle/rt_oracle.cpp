@@ -83,7 +83,13 @@ struct Counters {
     uint64_t aabb = 0, sph_miss = 0, sph_hit = 0, sq_behind = 0, sq_reject = 0, sq_hit = 0;
     uint64_t tri_par = 0, tri_u = 0, tri_v = 0, tri_full = 0, tri_upd = 0, leaf_refs = 0;
     uint64_t light_samples = 0;
+    /* of the above: the part spent inside Scene::phong calls whose colour the reference overwrites (a glass sphere hit with
+     * bounces left, R/src/Scene.h:626 then :705) -- closest-hit queries and algorithmic FLOP.  The reference executes it;
+     * an implementation that leaves it out renders the same image. */
+    uint64_t dead_rays = 0;
+    double dead_flops = 0.0;
     void operator+=(const Counters& o) {
+        dead_rays += o.dead_rays; dead_flops += o.dead_flops;
         rays += o.rays; samples += o.samples; nodes += o.nodes; aabb += o.aabb;
         sph_miss += o.sph_miss; sph_hit += o.sph_hit; sq_behind += o.sq_behind;
         sq_reject += o.sq_reject; sq_hit += o.sq_hit; tri_par += o.tri_par; tri_u += o.tri_u;
@@ -509,7 +515,11 @@ V3 phong(const OScene& s, const Hit& h, Rng& rng, Counters& c) {
 V3 trace(const OScene& s, const Ray& ray, int bounces, Rng& rng, Counters& c) {
     Hit h = closest_hit(s, ray, c);
     if (!h.hit) return V3();
+    const bool discarded = bounces > 0 && h.type == RT_SPHERE && material_of(s, h).type == RT_MAT_GLASS; /* :705 overwrites color */
+    const uint64_t rays_before = c.rays;
+    const double flops_before = discarded ? c.flops() : 0.0;
     V3 color = phong(s, h, rng, c);
+    if (discarded) { c.dead_rays += c.rays - rays_before; c.dead_flops += c.flops() - flops_before; }
     if (bounces > 0 && h.type == RT_SPHERE) {
         const rt_material& mat = material_of(s, h);
         V3 P = h.p, N = h.n, I = ray.d;
@@ -1148,6 +1158,11 @@ double orc_scene_counters(orc_scene* h, uint64_t out[16]) {
                       c.sq_hit, c.tri_par, c.tri_u, c.tri_v, c.tri_full, c.tri_upd, c.leaf_refs, c.light_samples};
     if (out) std::memcpy(out, v, sizeof(v));
     return c.flops();
+}
+/* Of those totals, what the reference computes and then discards (see Counters::dead_rays). */
+double orc_scene_discarded_work(orc_scene* h, uint64_t* rays) {
+    if (rays) *rays = h->total.dead_rays;
+    return h->total.dead_flops;
 }
 void orc_scene_counters_reset(orc_scene* h) { h->total = Counters(); }
 

@@ -109,6 +109,26 @@ def _spread_pixels(wl, n, seed, extra=()):
     return np.array(px, np.uint32)
 
 
+def test_c3_hundred_thousand_triangles_1080p():
+    """The 100 352-triangle frame at render level: closest hits, ~600 pixels of the 1920 x 1080 frame spread over walls,
+    spheres and mesh (the shading of R/src/Scene.h:319-422 on hits of R/src/Mesh.h:206-281, pooled shadow walks included),
+    and the tile / pass splits of the configuration's own 64 spp."""
+    wl, o, g = _pair("c3")
+    assert wl.desc.n_triangles == 100352 and (wl.w, wl.h, wl.spp) == (1920, 1080, 64)
+    info, _ = g.verify()
+    assert info.bvh_meshes == 1 and info.bvh_max_depth <= 32
+    _check_hits(wl, o, g, 900, 400, 700, 300, "c3")
+    # spread pixels plus a band over the mesh (image centre, lower half) and points on both spheres
+    rng = np.random.default_rng(11)
+    band = [(float(fx), float(fy)) for fx, fy in zip(rng.uniform(0.36, 0.64, 160), rng.uniform(0.55, 0.85, 160))]
+    px = _spread_pixels(wl, 420, 7, extra=band + [(0.5, 0.62), (0.45, 0.7), (0.55, 0.75), (0.62, 0.68), (0.4, 0.66), (0.5, 0.8),
+                                                   (0.37, 0.72), (0.63, 0.7), (0.36, 0.68), (0.64, 0.74)])
+    _, st = _check_pixels(wl, o, g, px, 1, seed=2)
+    assert st.bvh_nodes > 0 and st.bvh_tris > 0
+    _check_splits(wl, g, wl.spp, 16, (2, 4, 8), seed=3)
+    g.close()
+
+
 def test_c4_one_million_triangles_4k():
     wl, o, g = _pair("c4")
     assert wl.desc.n_triangles == 1002528 and (wl.w, wl.h, wl.spp) == (3840, 2160, 256)

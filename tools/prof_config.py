@@ -17,6 +17,7 @@ ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--pass-spp", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--rank", type=int, default=0)
+ap.add_argument("--tile", type=int, default=16, help="tile edge (bench.py renders 8 x 8 tiles)")
 a = ap.parse_args()
 api.init(0)
 dev = torch.device("cuda", 0)
@@ -25,7 +26,8 @@ scene = wl.upload()
 w, h, spp = wl.w, wl.h, a.spp or wl.spp
 pass_spp = min(a.pass_spp or wl.pass_spp, spp)
 cam = wl.camera()
-lay = parallel_render.TileLayout(w, h, 16, 16, a.world)
+T = a.tile
+lay = parallel_render.TileLayout(w, h, T, T, a.world)
 out = torch.zeros(lay.buffer_floats(), dtype=torch.float32, device=dev)
 cnt = parallel_render.new_counters(dev)
 stream = torch.cuda.current_stream(dev)
@@ -34,7 +36,7 @@ for i in range(a.steps):
     cnt.zero_()
     e0.record(stream)
     for s0 in range(0, spp, pass_spp):
-        scene.render_pass_device(cam, w, h, min(pass_spp, spp - s0), s0, spp, 1, 16, 16, a.rank, a.world, out.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
+        scene.render_pass_device(cam, w, h, min(pass_spp, spp - s0), s0, spp, 1, T, T, a.rank, a.world, out.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
     e1.record(stream)
     torch.cuda.synchronize()
     t = cnt.sum(0).tolist()
