@@ -21,6 +21,14 @@
 
 #define RT_DEV __device__ __forceinline__
 
+/* Attribution switches (RT_EXP_*) leave a part of the work out to see what it costs; every one of them renders WRONG images.
+ * They only compile in builds that say so (tools/ab.sh passes -DRT_ATTRIBUTION_BUILD), never in the library proper. */
+#if (defined(RT_EXP_NO_MESH_CLOSEST) || defined(RT_EXP_NO_MESH_SHADOW) || defined(RT_EXP_NO_WALK) || defined(RT_EXP_CHEAP_RNG) || \
+     defined(RT_EXP_NO_RENORM) || defined(RT_EXP_FLOAT_POW) || defined(RT_EXP_NO_LIGHT_TERM) || defined(RT_EXP_NO_SPHERES) ||      \
+     defined(RT_EXP_NO_SQUARES) || defined(RT_EXP_NO_SHADE) || defined(RT_EXP_NO_SHADOW_TESTS)) && !defined(RT_ATTRIBUTION_BUILD)
+#error "RT_EXP_* switches change the image: attribution builds only (-DRT_ATTRIBUTION_BUILD, see tools/ab.sh)"
+#endif
+
 struct f3 { float x, y, z; };
 
 RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -43,10 +51,11 @@ RT_DEV float len3(f3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a
  * 2^32 pre-scale for tiny inputs, v_sqrt, a one-ulp-down / one-ulp-up residual test and a
  * special-value select.  For operands in a "plain" range (|x| in [2^-40, 2^40] below) v_div_scale
  * returns its input unscaled with VCC = 0, v_div_fmas is then an ordinary FMA, v_div_fixup passes
- * the quotient through and the sqrt pre-scale is not taken -- so the helpers below run exactly the
- * compiler's remaining instructions and return bit-identical results, while a normalisation
- * shares one refined reciprocal between its three quotients.  Anything outside the range (zero,
- * subnormal, huge, NaN components) takes the ordinary operators. */
+ * the quotient through and the sqrt pre-scale is not taken -- so the helpers below run the compiler's
+ * remaining instructions (the division: one of its two quotient corrections, see div_plain) and
+ * return bit-identical results, while a normalisation shares one refined reciprocal between its
+ * three quotients.  Anything outside the range (zero, subnormal, huge, NaN components) takes the
+ * ordinary operators. */
 RT_DEV float sqrt_plain(float x) { /* x in [2^-96, FLT_MAX] */
     float s = __builtin_amdgcn_sqrtf(x);
     float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
@@ -59,9 +68,13 @@ RT_DEV float rcp_refined(float b) {
     float r = __builtin_amdgcn_rcpf(b);
     return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
 }
-RT_DEV float div_plain(float a, float b, float r) { /* r = rcp_refined(b) */
+/* a / b, r = rcp_refined(b): the product a * r and ONE correction by the exact remainder.  The compiler's sequence corrects twice;
+ * once is enough here: on gfx950 rcp_refined returns the correctly rounded reciprocal of every significand, and with it the
+ * single step yields the correctly rounded quotient for every pair of significands -- checked over all 2^23 x 2^23 pairs
+ * (7.04e13 quotients, tools/micro/div_check.hip; the uncorrected product is off by one in 27 % of them), and scaling either
+ * operand by a power of two scales every intermediate exactly while nothing leaves the plain range. */
+RT_DEV float div_plain(float a, float b, float r) {
     float q = a * r;
-    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
     return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
 }
 /* normalize() of R/src/Vec3.h:34: L = sqrt(x^2 + y^2 + z^2), three true divides by L; also returns L */
@@ -670,6 +683,9 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
     /* tables walked directly with one-ahead record fetches, as in root_closest */
     /* Per object the cheap part runs for all rays of the batch first, in straight-line code, and the rare
      * expensive part sits behind ONE wave-level branch per object instead of one per ray. */
+#ifdef RT_EXP_NO_SPHERES /* attribution: the sphere tests of the shadow rays */
+    if (0)
+#endif
     for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& s, uint32_t si) {
         f3 oc = o - ld3(s.c);
         float c; /* |o - c|^2 - r^2 depends on the origin only: the caller computed it for the first spheres (sphere_c) */
@@ -682,7 +698,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
         bool some = false;
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
-            float a = dot3(d[j], d[j]);
+            float a = dot3(d[j], d[j]); /* terms of the direction alone: the compiler moves them out of the loop over the spheres */
             b[j] = dot3(2.f * d[j], oc);
             delta[j] = b[j] * b[j] - 4.f * a * c;
             some = some || delta[j] >= 0.f;
@@ -734,6 +750,10 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
     };
     /* sq_mask (the same in every lane): bit q clear = no ray of this shaded point can meet square q (shade decides that
      * once per point), and the square is not even fetched.  Scenes with more than 32 squares test them all. */
+#ifdef RT_EXP_NO_SQUARES /* attribution: the square tests of the shadow rays */
+    if (0) {}
+    else
+#endif
     if (sc.n_squares > 32u || sq_mask == 0xffffffffu) for_each_record(sc.squares, sc.n_squares, square);
     else if (sq_mask) {
         uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)sq_mask);
@@ -793,7 +813,11 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
 struct Rng {
     uint32_t key, k;
     /* (float)rand() / RAND_MAX with RAND_MAX converted to float = 2^31 (R/src/Scene.h:259-260) */
+#ifdef RT_EXP_CHEAP_RNG /* attribution: what the three integer multiplies and six shift / xor steps of a draw cost */
+    RT_DEV float unit() { return (float)(int)(((key + (k++) * 0x9E3779B9U) ^ 0x5bd1e995U) >> 1) / 2147483648.f; }
+#else
     RT_DEV float unit() { return (float)(int)rt_rand31(key, k++) / 2147483648.f; }
+#endif
 };
 
 /* Light sample i of a shaded point (Scene::samplePointOnLight, R/src/Scene.h:252-276): calls k + 2 i and
@@ -1032,13 +1056,24 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
  * squarings, anything else through the double pow; rounded once to float. */
 __device__ __attribute__((noinline)) float pow_general(float x, float y) { return (float)pow((double)x, (double)y); }
 RT_DEV float pow_shiny(float x, float y) {
+#ifdef RT_EXP_FLOAT_POW /* attribution: the double squarings */
+    if (y == 16.0f) { float a = x; a *= a; a *= a; a *= a; a *= a; return a; }
+#endif
     if (y == 16.0f) { double a = (double)x; a *= a; a *= a; a *= a; a *= a; return (float)a; }
     if (y == 0.0f) return 1.0f;
     return pow_general(x, y); /* kept out of line: the double pow is large and rarely runs */
 }
 
 /* Scene::computeLightContribution, R/src/Scene.h:304-316 */
-/* all16 (the same in every lane): every lane's material has shininess 16, so the exponent needs no per-lane branches */
+/* all16 (the same in every lane): every lane's material has shininess 16, so the exponent needs no per-lane branches.
+ * The light term feeds nothing but the colour -- no hit / miss decision, no branch of the path, no draw of the random
+ * stream depends on it -- so it is the one place where the arithmetic is not the reference's operation for operation: fused
+ * multiply-adds, and the normalisation of the mirrored direction through v_rsq_f32 with one Newton step instead of a square
+ * root and three divisions.  Each of its results lies within a few units in the last place of the reference's (whose own
+ * unfused arithmetic is that far from the exact value): the colours agree to 1e-6 where they agreed to 1e-7, against a
+ * tolerance of 40 dB.  RT_EXACT_LIGHT_TERM builds the reference's sequence instead (19.2 -> 18.0 ms on the Cornell frame
+ * without it). */
+#ifdef RT_EXACT_LIGHT_TERM
 RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V, f3 L, bool all16 = false) {
     f3 R = norm3_unit((2.f * dot3(N, L)) * N - L);
     float nl = max_std(0.f, dot3(L, N));
@@ -1049,6 +1084,24 @@ RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V
     sum.y += lt.color[1] * m.kd[1] * nl; sum.y += lt.color[1] * m.ks[1] * sp;
     sum.z += lt.color[2] * m.kd[2] * nl; sum.z += lt.color[2] * m.ks[2] * sp;
 }
+#else
+RT_DEV float fdot3(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RT_DEV void light_term(f3& sum, const DLight& lt, const DMaterial& m, f3 N, f3 V, f3 L, bool all16 = false) {
+    const float nl0 = fdot3(N, L), two = 2.f * nl0;
+    const f3 R = mk3(__builtin_fmaf(two, N.x, -L.x), __builtin_fmaf(two, N.y, -L.y), __builtin_fmaf(two, N.z, -L.z));
+    const float rr = fdot3(R, R);
+    float inv = __builtin_amdgcn_rsqf(rr);
+    inv = inv * __builtin_fmaf(-0.5f * rr, inv * inv, 1.5f); /* one Newton step: 1 / |R| to the last bit or two */
+    const float rv = max_std(0.f, fdot3(R, V) * inv);
+    const float nl = max_std(0.f, nl0);
+    float sp;
+    if (all16) sp = pow_shiny(rv, 16.0f);
+    else sp = pow_shiny(rv, m.shininess);
+    sum.x = __builtin_fmaf(lt.color[0] * m.kd[0], nl, sum.x); sum.x = __builtin_fmaf(lt.color[0] * m.ks[0], sp, sum.x);
+    sum.y = __builtin_fmaf(lt.color[1] * m.kd[1], nl, sum.y); sum.y = __builtin_fmaf(lt.color[1] * m.ks[1], sp, sum.y);
+    sum.z = __builtin_fmaf(lt.color[2] * m.kd[2], nl, sum.z); sum.z = __builtin_fmaf(lt.color[2] * m.ks[2], sp, sum.z);
+}
+#endif
 
 RT_DEV int material_index(const DeviceScene& sc, int type, int obj) {
     return type == RT_SPHERE ? ldc(&sc.spheres[obj].mat) : (type == RT_SQUARE ? ldc(&sc.squares[obj].mat) : ldc(&sc.meshes[obj].mat));
@@ -1125,9 +1178,19 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                         f3 SP = S - P;
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
+#ifdef RT_EXP_NO_RENORM /* attribution: the second normalisation of every shadow ray */
+                        Ld[j] = L[j];
+#else
                         Ld[j] = norm3_unit(L[j]); /* Ray() normalises L again */
+#endif
                     }
+#ifdef RT_EXP_NO_SHADOW_TESTS /* attribution: light samples, both normalisations and light terms without the object tests */
+                    near4 = 0;
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) occ[j] = Ld[j].x + dist[j] > 1e30f;
+#else
                     shadow_batch<M, SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask, sph_c);
+#endif
                     bool now = true; /* every ray of the batch is decided: add the light terms in sample order right away */
                     if (M & RT_M_BVH) {
                         if (first_open == 16 && __ballot(near4 != 0u) != 0ull) first_open = (uint32_t)i0;
@@ -1136,6 +1199,11 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         for (int j = 0; j < SB; ++j) dark |= (occ[j] ? 1u : 0u) << (i0 + j);
                         near |= near4 << i0;
                     }
+#ifdef RT_EXP_NO_LIGHT_TERM /* attribution: the light terms of the unoccluded samples */
+                    now = false;
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) sum.x += occ[j] ? 0.f : L[j].x;
+#endif
                     if (now) {
 #pragma unroll
                         for (int j = 0; j < SB; ++j)
@@ -1297,6 +1365,9 @@ RT_DEV f3 trace_path(const DeviceScene& sc, f3 o, f3 d, Rng& rng, Cnt& cnt) {
             int mat = 0, mtype = RT_MAT_DIFFUSE;
             if (bounces) { mat = ldc(&sc.spheres[h.obj].mat); mtype = ldc(&sc.materials[mat].type); }
             if (PROBE) { if (++cnt.nodes >= RT_PROBE_CAP) return ret; }
+#ifdef RT_EXP_NO_SHADE /* attribution: everything but Scene::phong */
+            else if (true) { skip_shade(sc, rng, cnt); col = mk3(0.07f, 0.07f, 0.07f); }
+#endif
             else if (mtype == RT_MAT_GLASS) skip_shade(sc, rng, cnt);
             else col = shade<M, SB>(sc, h, rng, cnt);
             ret = col;
