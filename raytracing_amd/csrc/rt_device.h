@@ -694,16 +694,40 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
 #pragma unroll
             for (uint32_t k = 1; k < RT_SPH_KEPT; ++k) c = si == k ? sph_c[k] : c;
         } else c = sphere_c(s, o);
-        float b[SB], delta[SB];
+        float b[SB], delta[SB], bb[SB], ac4[SB];
         bool some = false;
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             float a = dot3(d[j], d[j]); /* terms of the direction alone: the compiler moves them out of the loop over the spheres */
             b[j] = dot3(2.f * d[j], oc);
-            delta[j] = b[j] * b[j] - 4.f * a * c;
+            bb[j] = b[j] * b[j];
+            ac4[j] = 4.f * a * c;
+            delta[j] = bb[j] - ac4[j];
             some = some || delta[j] >= 0.f;
         }
         if (!some) return; /* every line of the batch misses the sphere */
+#ifndef RT_NO_SPHERE_CERT
+        /* A line that meets the sphere is not yet a ray that meets it before the light: rays that leave the sphere they start
+         * on, and rays whose line reaches a sphere only behind their origin or beyond the light, are most of the lines that get
+         * here.  Both cases are certain before any square root or division (a = d . d lies within 3e-7 of 1):
+         *   behind: b > 0 and 4ac > 1e-5 b^2.  Then c > 0, the float discriminant is at most b^2 (1 - 1e-5 + 2^-23), its root
+         *           is smaller than b, both numerators -b -+ sq are negative and neither root is > 0: the reference reports
+         *           no intersection (for a zero discriminant -b / 2a < 0 says the same).
+         *   beyond: b < 0, c > 0 and, with m = -b and D = 1.001 dist: m > 2.001 D (the vertex of the quadratic lies beyond D),
+         *           c > D (m - 0.999 D) (the quadratic is positive at D) and m < 1000 dist (which bounds the cancellation in
+         *           m - sq to a relative 1e-4): the smaller root computed in floats is larger than dist, so is the one the
+         *           reference picks, and `t < dist` fails.
+         * Only a batch with a ray that is neither goes on to the roots. */
+        bool need = false;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const float m = -b[j], D = 1.001f * dist[j];
+            const bool behind = b[j] > 0.f && ac4[j] > 1e-5f * bb[j];
+            const bool beyond = m > 2.001f * D && c * 0.999f > D * (m - 0.999f * D) && m < 1000.f * dist[j] && c > 0.f;
+            need = need || (delta[j] >= 0.f && !behind && !beyond);
+        }
+        if (!need) return;
+#endif
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             float a = dot3(d[j], d[j]);
