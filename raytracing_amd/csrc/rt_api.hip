@@ -467,6 +467,7 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
     d.n_kd = (uint32_t)r->host.kd.size(); d.n_refs = (uint32_t)r->host.refs.size();
     for (int a = 0; a < 3; ++a) { d.box_lo[a] = r->host.box_lo[a]; d.box_hi[a] = r->host.box_hi[a]; }
     d.kd_epsilon = r->host.kd_epsilon;
+    d.cert_radius = r->host.cert_radius;
     d.root_is_leaf = (!r->host.kd.empty() && r->host.kd[0].leaf) ? 1 : 0;
     r->mode = (d.root_is_leaf ? 0 : RT_M_KD) | (r->n_bvh ? RT_M_BVH : 0);
     for (const DSphere& sp : r->host.spheres) {
@@ -613,6 +614,11 @@ int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normal
     HIP_TRY(hipStreamSynchronize(g.stream));
     if (device_ms) HIP_TRY(hipEventElapsedTime(device_ms, g.ev0, g.ev1));
     for (int a = 0; a < 3; ++a) { r->host.box_lo[a] = r->dev.box_lo[a] = root_lo[a]; r->host.box_hi[a] = r->dev.box_hi[a] = root_hi[a]; }
+    { /* the margins of the light / square table were derived for the root box of the build: a box that outgrew them switches the table off */
+        float far = 0.f;
+        for (int a = 0; a < 3; ++a) far = std::max(far, std::max(std::fabs(root_lo[a]), std::fabs(root_hi[a])));
+        if (!(std::sqrt(3.0f) * far + 0.002f <= r->dev.cert_radius)) r->dev.light_sq = nullptr;
+    }
     g.order_last_slot = -1; /* a launch order or deep list probed before the vertices moved is not used again */
     return RT_OK;
 }

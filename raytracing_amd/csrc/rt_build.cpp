@@ -531,20 +531,6 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defe
         out.lights.push_back(o);
     }
 
-    /* which side of every square's plane the corners of every quad light lie on (DeviceScene::light_sq) */
-    for (const DLight& l : out.lights)
-        for (const DSquare& q : out.squares) {
-            const float nan = std::numeric_limits<float>::quiet_NaN();
-            float rec[4] = {nan, nan, nan, nan};
-            if (l.type == RT_LIGHT_QUAD) {
-                const float* corner[3] = {l.p0, l.p1, l.p2};
-                for (int i = 0; i < 3; ++i)
-                    rec[i] = (q.v0[0] - corner[i][0]) * q.n[0] + (q.v0[1] - corner[i][1]) * q.n[1] + (q.v0[2] - corner[i][2]) * q.n[2];
-                rec[3] = 2e-4f * len(ld(q.n));
-            }
-            out.light_sq.insert(out.light_sq.end(), rec, rec + 4);
-        }
-
     /* root box: Scene::computeGlobalAABB, R/src/Scene.h:133-166 */
     Box root;
     for (uint32_t i = 0; i < d.n_meshes; ++i)
@@ -558,6 +544,60 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defe
         grow(root, lo); grow(root, hi);
     }
     for (int a = 0; a < 3; ++a) { out.box_lo[a] = root.lo[a]; out.box_hi[a] = root.hi[a]; }
+
+    /* DLightSq per (quad light, square): see rt_types.h.  R bounds |X| for every point the rules are applied to (shadow origins
+     * inside the root box, light samples, their 0.001 offsets); a float dot(v0 - X, n) or dot(X - v0, w) then carries a rounding
+     * error below 1e-6 (|v0| + R) |n| resp. |w|, a light sample computed in floats lies within 1e-6 R of its exact place, and the
+     * end of a shadow ray (two normalisations, one length) within 2e-6 R of sample + 0.001 N. */
+    {
+        double R = 0.0;
+        for (int a = 0; a < 3; ++a) R = std::max(R, (double)std::max(std::fabs(root.lo[a]), std::fabs(root.hi[a])));
+        for (const DLight& l : out.lights)
+            for (const float* c : {l.p0, l.p1, l.p2, l.pos})
+                for (int a = 0; a < 3; ++a) R = std::max(R, (double)std::fabs(c[a]));
+        R = std::sqrt(3.0) * R + 0.002;
+        out.cert_radius = std::isfinite(R) ? (float)R : 0.f;
+        const float nan = std::numeric_limits<float>::quiet_NaN();
+        for (const DLight& l : out.lights)
+            for (const DSquare& q : out.squares) {
+                DLightSq r;
+                float* f = &r.h0;
+                for (int i = 0; i < 20; ++i) f[i] = nan;
+                const double nl = std::sqrt((double)q.n[0] * q.n[0] + (double)q.n[1] * q.n[1] + (double)q.n[2] * q.n[2]);
+                const double v0l = std::sqrt((double)q.v0[0] * q.v0[0] + (double)q.v0[1] * q.v0[1] + (double)q.v0[2] * q.v0[2]);
+                if (l.type == RT_LIGHT_QUAD && std::isfinite(R) && nl > 0.0 && std::isfinite(nl)) {
+                    const float* corner[3] = {l.p0, l.p1, l.p2};
+                    auto dotd = [](const float* a, const float* b, const float* c) { /* dot(a - b, c) in double */
+                        return ((double)a[0] - b[0]) * c[0] + ((double)a[1] - b[1]) * c[1] + ((double)a[2] - b[2]) * c[2];
+                    };
+                    double g[3], pw[3], pk[3];
+                    for (int i = 0; i < 3; ++i) { g[i] = dotd(q.v0, corner[i], q.n); pw[i] = dotd(corner[i], q.v0, q.w); pk[i] = dotd(corner[i], q.v0, q.h); }
+                    const double wl = std::sqrt((double)q.w[0] * q.w[0] + (double)q.w[1] * q.w[1] + (double)q.w[2] * q.w[2]);
+                    const double kl = std::sqrt((double)q.h[0] * q.h[0] + (double)q.h[1] * q.h[1] + (double)q.h[2] * q.h[2]);
+                    const double a_max = (v0l + R) * nl;                 /* bound of any |numerator| */
+                    const double delta = 8e-6 * a_max;                   /* rounding of numerators and of g evaluated in floats, sample and ray-end placement */
+                    r.h0 = (float)g[0]; r.e1 = (float)(g[1] - g[0]); r.e2 = (float)(g[2] - g[0]);
+                    r.g_min = (float)std::min(g[0], std::min(g[1], g[2])); r.g_max = (float)std::max(g[0], std::max(g[1], g[2]));
+                    r.a_sign = (float)(2.0 * delta);
+                    r.t_miss = (float)(0.001001 * nl + 2e-5 * a_max + 2.0 * delta);
+                    r.t_hit = r.t_miss; /* |g| beyond the same margin on the other side: 0 < t < |S - P| (t > 0 needs no margin of its own) */
+                    /* the accepted intervals of the rectangle test, shrunk by what the projections can be off: rounding for the
+                     * origin's own (ow / ok), rounding plus the 0.001 N between a sample and the end of its ray for the sample's */
+                    const double mo_w = 1e-5 * (v0l + R) * wl, mo_k = 1e-5 * (v0l + R) * kl;
+                    const double ms_w = 0.001001 * wl + mo_w, ms_k = 0.001001 * kl + mo_k;
+                    const double cw = 0.5 * ((double)q.w_lo + q.w_hi), ck = 0.5 * ((double)q.h_lo + q.h_hi);
+                    const double half_w = 0.5 * ((double)q.w_hi - q.w_lo), half_k = 0.5 * ((double)q.h_hi - q.h_lo);
+                    r.cw = (float)cw; r.ck = (float)ck;
+                    r.w0 = (float)(pw[0] - cw); r.w1 = (float)(pw[1] - pw[0]); r.w2 = (float)(pw[2] - pw[0]);
+                    r.k0 = (float)(pk[0] - ck); r.k1 = (float)(pk[1] - pk[0]); r.k2 = (float)(pk[2] - pk[0]);
+                    r.rw = (float)(half_w > ms_w ? half_w - ms_w : -1.0); r.rk = (float)(half_k > ms_k ? half_k - ms_k : -1.0);
+                    r.ow = (float)(half_w > mo_w ? half_w - mo_w : -1.0); r.ok = (float)(half_k > mo_k ? half_k - mo_k : -1.0);
+                    for (int i = 0; i < 20; ++i) /* a record that is not finite decides nothing */
+                        if (!std::isfinite(f[i])) { for (int j = 0; j < 20; ++j) f[j] = nan; break; }
+                }
+                out.light_sq.push_back(r);
+            }
+    }
 
     /* KDTree::buildKDTree, R/src/KDTree.cpp:477-519: spheres, squares, meshes */
     for (uint32_t i = 0; i < d.n_spheres; ++i) out.refs.push_back(DRef{RT_SPHERE, (int32_t)i});

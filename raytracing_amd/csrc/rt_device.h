@@ -25,7 +25,7 @@
  * They only compile in builds that say so (tools/ab.sh passes -DRT_ATTRIBUTION_BUILD), never in the library proper. */
 #if (defined(RT_EXP_NO_MESH_CLOSEST) || defined(RT_EXP_NO_MESH_SHADOW) || defined(RT_EXP_NO_WALK) || defined(RT_EXP_CHEAP_RNG) || \
      defined(RT_EXP_NO_RENORM) || defined(RT_EXP_FLOAT_POW) || defined(RT_EXP_NO_LIGHT_TERM) || defined(RT_EXP_NO_SPHERES) ||      \
-     defined(RT_EXP_NO_SQUARES) || defined(RT_EXP_NO_SHADE) || defined(RT_EXP_NO_SHADOW_TESTS)) && !defined(RT_ATTRIBUTION_BUILD)
+     defined(RT_EXP_NO_SQUARES) || defined(RT_EXP_NO_SHADE) || defined(RT_EXP_NO_SHADOW_TESTS) || defined(RT_EXP_SKIP_SQUARE) || defined(RT_EXP_COUNT_OPEN) || defined(RT_EXP_DROP_OPEN)) && !defined(RT_ATTRIBUTION_BUILD)
 #error "RT_EXP_* switches change the image: attribution builds only (-DRT_ATTRIBUTION_BUILD, see tools/ab.sh)"
 #endif
 
@@ -666,13 +666,66 @@ RT_DEV float sphere_c(const DSphere& s, f3 o) {
 #ifndef RT_SB0
 #define RT_SB0 2
 #endif
+struct SquareRules { /* per shaded point and light, the same in every lane: which squares its shadow rays still test, and how (shade) */
+    uint32_t test;       /* bit q clear: no ray of this point can meet square q, it is not even fetched */
+    uint32_t by_sample;  /* bit q: DLightSq decides most rays of square q from the light sample's (u, v) */
+    uint32_t flipped;    /* ... with the origin on the negative side of the plane */
+    uint32_t can_hit;    /* ... and certain hits may be taken (every lane's origin projects well inside the rectangle) */
+    const DLightSq* rec; /* the light's row of DeviceScene::light_sq */
+};
+/* The squares of rules.by_sample against the light samples (u, v) of a batch, before their rays even exist: fused arithmetic
+ * against margins (DLightSq), no quotient.  Sets hidden[j] when a square is known to hide ray j and returns the squares that
+ * some ray of the wave still has to test with their own arithmetic -- which then runs for every ray of the wave and finds
+ * again what the rules knew.  Records are requested one ahead, like the object records of the tests proper; the side of the
+ * plane goes into the sign bits of the record's three coefficients (the same in every lane: scalar instructions). */
+template <int SB>
+RT_DEV uint32_t sample_rules(const SquareRules& rules, const float (&bu)[SB], const float (&bv)[SB], bool (&hidden)[SB]) {
+    uint32_t test = rules.test;
+#pragma unroll
+    for (int j = 0; j < SB; ++j) hidden[j] = false;
+    uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)rules.by_sample);
+    if (!left) return test;
+    auto one = [&](const DLightSq& t, uint32_t k) {
+        const int flip = ((rules.flipped >> k) & 1u) ? (int)0x80000000 : 0;
+        const float h0 = __int_as_float(__float_as_int(t.h0) ^ flip), e1 = __int_as_float(__float_as_int(t.e1) ^ flip),
+                    e2 = __int_as_float(__float_as_int(t.e2) ^ flip);
+        const bool can_hit = ((rules.can_hit >> k) & 1u) != 0u;
+        bool any_open = false;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const float g = __builtin_fmaf(bu[j], e1, __builtin_fmaf(bv[j], e2, h0));
+            bool decided = g > t.t_miss;
+            if (can_hit) {
+                const bool hit = g < -t.t_hit && __builtin_fabsf(__builtin_fmaf(bu[j], t.w1, __builtin_fmaf(bv[j], t.w2, t.w0))) < t.rw &&
+                                 __builtin_fabsf(__builtin_fmaf(bu[j], t.k1, __builtin_fmaf(bv[j], t.k2, t.k0))) < t.rk;
+                hidden[j] = hidden[j] || hit;
+                decided = decided || hit;
+            }
+            any_open = any_open || !decided;
+        }
+        if (!__ballot(any_open)) test &= ~(1u << k);
+    };
+    uint32_t k = (uint32_t)__builtin_ctz(left);
+    DLightSq a = ldc(&rules.rec[k]);
+    for (;;) {
+        left &= left - 1u;
+        if (!left) { one(a, k); break; }
+        const uint32_t k2 = (uint32_t)__builtin_ctz(left);
+        const DLightSq b = ldc(&rules.rec[k2]);
+        one(a, k);
+        a = b; k = k2;
+    }
+    return test;
+}
 template <int M, int SB>
 RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&d)[SB], const float (&dist)[SB], bool (&occ)[SB], uint32_t& near,
                          Cnt& cnt, uint32_t sq_mask, const float (&sph_c)[RT_SPH_KEPT]) {
+    /* sq_mask (the same in every lane): the squares some ray of the wave still has to test; occ[j] comes in true for a ray a
+     * square is already known to hide (sample_rules) */
     bool act[SB];
     cnt.rays += SB;
 #pragma unroll
-    for (int j = 0; j < SB; ++j) { act[j] = true; occ[j] = false; }
+    for (int j = 0; j < SB; ++j) act[j] = true;
     if (__builtin_expect(!o_inside, 0)) { /* the origin left the root box: the slab test decides, ray by ray */
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
@@ -1161,25 +1214,38 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
             if (!(M & RT_M_KD)) {
                 const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
                 const Rng at_first = rng; /* the stream position of light sample 0 */
-                /* Squares no shadow ray of this point can meet.  A ray runs from so to S + 0.001 N, S a mix of the light's
-                 * corners: when so and the three shifted corners lie on one side of a square's plane, each further from
-                 * it than 2e-4 (rounding moves them by 1e-6 at most), the ray crosses the plane before its origin or more
-                 * than 1e-5 of its length beyond its end, so the reference's t fails 0 <= t < |S - P| whatever its last
-                 * bits are.  Walls seen from inside the box are such squares; what remains is usually the light's own
-                 * plane and the ceiling.  A square stays if any lane of the wave needs it (NaN keeps it too). */
-                uint32_t sq_mask = 0xffffffffu;
-                if (sc.n_squares <= 32u && sc.light_sq) {
-                    sq_mask = 0u;
-                    const float* side = sc.light_sq + 4u * li * sc.n_squares;
+                /* What this point's shadow rays still have to test of every square (SquareRules, DLightSq).  The side of a
+                 * square's plane the origin lies on must be the same, by the margin a_sign, in every lane of the wave; then a
+                 * square with all three corners of the light on that side beyond t_miss is missed by every sample -- walls seen
+                 * from inside the box -- and for the others the samples decide ray by ray.  NaN records (point lights) and
+                 * origins outside the root box decide nothing: every ray then tests every square. */
+                SquareRules rules;
+                rules.test = 0xffffffffu; rules.by_sample = 0u; rules.flipped = 0u; rules.can_hit = 0u;
+                rules.rec = sc.light_sq ? sc.light_sq + (size_t)li * sc.n_squares : nullptr;
+                if (sc.n_squares <= 32u && sc.light_sq && __ballot(!so_inside) == 0ull) {
+                    rules.test = 0u;
                     for_each_record(sc.squares, sc.n_squares, [&](const DSquare& q, uint32_t k) {
-                        const f3 n = ld3(q.n);
-                        const float num = dot3(ld3(q.v0) - so, n), shift = 0.001f * dot3(N, n);
-                        const float g0 = ldc(&side[4u * k]) - shift, g1 = ldc(&side[4u * k + 1u]) - shift, g2 = ldc(&side[4u * k + 2u]) - shift;
-                        const float m = ldc(&side[4u * k + 3u]);
-                        const bool apart = (num > m && g0 > m && g1 > m && g2 > m) || (num < -m && g0 < -m && g1 < -m && g2 < -m);
-                        if (__ballot(!apart)) sq_mask |= 1u << k;
+                        const DLightSq t = ldc(&rules.rec[k]);
+                        const f3 vo = ld3(q.v0) - so;
+                        const float num = dot3(vo, ld3(q.n));
+                        const bool all_pos = __ballot(!(num > t.a_sign)) == 0ull, all_neg = __ballot(!(num < -t.a_sign)) == 0ull;
+                        bool keep = true;
+                        if (all_pos || all_neg) {
+                            if (all_pos ? t.g_min > t.t_miss : t.g_max < -t.t_miss) keep = false;
+                            else {
+                                rules.by_sample |= 1u << k;
+                                if (all_neg) rules.flipped |= 1u << k;
+                                const bool in = __builtin_fabsf(-dot3(vo, ld3(q.w)) - t.cw) < t.ow && __builtin_fabsf(-dot3(vo, ld3(q.h)) - t.ck) < t.ok;
+                                const bool beyond = all_pos ? t.g_min < -t.t_hit : t.g_max > t.t_hit; /* some sample can lie on the far side */
+                                if (beyond && __ballot(!in) == 0ull) rules.can_hit |= 1u << k;
+                            }
+                        }
+                        if (keep) rules.test |= 1u << k;
                     });
                 }
+#ifdef RT_EXP_SKIP_SQUARE /* attribution: the shadow tests of one square */
+                rules.test &= ~(1u << RT_EXP_SKIP_SQUARE);
+#endif
                 float sph_c[RT_SPH_KEPT];
 #pragma unroll
                 for (uint32_t k = 0; k < RT_SPH_KEPT; ++k) sph_c[k] = k < sc.n_spheres ? sphere_c(ldc(&sc.spheres[k]), so) : 0.f;
@@ -1191,7 +1257,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                 uint32_t first_open = 16; /* wave-uniform: the first sample whose light term is still to be added */
                 for (int i0 = 0; i0 < 16; i0 += SB) {
                     f3 L[SB], Ld[SB];
-                    float dist[SB];
+                    float dist[SB], bu[SB], bv[SB];
                     bool occ[SB];
                     uint32_t near4;
 #pragma unroll
@@ -1199,6 +1265,19 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         float u = rng.unit();
                         float v = rng.unit();
                         if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+                        bu[j] = u; bv[j] = v;
+                    }
+#if defined(RT_EXP_COUNT_OPEN) /* attribution: how often a square with sample rules still needs its own arithmetic (counts land in rt_stats) */
+                    const uint32_t sq_test = sample_rules<SB>(rules, bu, bv, occ);
+                    cnt.bvh_tris += (sq_test >> RT_EXP_COUNT_OPEN) & 1u; cnt.bvh_nodes += (rules.by_sample >> RT_EXP_COUNT_OPEN) & 1u; cnt.nodes += 1000u * ((rules.can_hit >> RT_EXP_COUNT_OPEN) & 1u);
+#elif defined(RT_EXP_DROP_OPEN) /* attribution: the cost of the rules alone (squares they leave open are not tested) */
+                    const uint32_t sq_test = sample_rules<SB>(rules, bu, bv, occ) & ~rules.by_sample;
+#else
+                    const uint32_t sq_test = sample_rules<SB>(rules, bu, bv, occ);
+#endif
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        const float u = bu[j], v = bv[j];
                         f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
                         f3 SP = S - P;
                         L[j] = norm3_len(SP, dist[j]); /* dist = |S - P|, the same sqrt the normalisation takes */
@@ -1213,7 +1292,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
 #pragma unroll
                     for (int j = 0; j < SB; ++j) occ[j] = Ld[j].x + dist[j] > 1e30f;
 #else
-                    shadow_batch<M, SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_mask, sph_c);
+                    shadow_batch<M, SB>(sc, so, so_inside, Ld, dist, occ, near4, cnt, sq_test, sph_c);
 #endif
                     bool now = true; /* every ray of the batch is decided: add the light terms in sample order right away */
                     if (M & RT_M_BVH) {

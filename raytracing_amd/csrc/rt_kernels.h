@@ -80,7 +80,11 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
     constexpr int N = RT_COUNTER_FIELDS;
     if (ONE_WAVE) {
         uint32_t t[N] = {wave_total(c.rays), wave_total(samples), wave_total(c.nodes), 0u, 0u, wave_total(c.skipped)};
+#ifdef RT_EXP_COUNT_OPEN
+        if (true) { t[3] = wave_total(c.bvh_nodes); t[4] = wave_total(c.bvh_tris); }
+#else
         if (M & RT_M_BVH) { t[3] = wave_total(c.bvh_nodes); t[4] = wave_total(c.bvh_tris); }
+#endif
         uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) mine = (int)threadIdx.x == k ? t[k] : mine;

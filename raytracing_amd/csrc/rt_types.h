@@ -86,6 +86,29 @@ struct DBvh4Node {
     DBvhNode half[2];
 };
 
+/* Shadow rays of a quad light against a square, decided without the square's arithmetic.  A sample of the light is
+ * S(u, v) = (1 - u - v) p0 + u p1 + v p2 (R/src/Scene.h:252-276), its shadow ray runs from so = P + 0.001 N along S - P for
+ * the length |S - P|, i.e. to S + 0.001 N.  The numerator of Square::intersect, dot(v0 - X, n) (R/src/Square.h:86-88), is
+ * affine in X, so at the far end it is g(u, v) = h0 + u e1 + v e2 up to 0.001 |n| and rounding; where the ray crosses the plane
+ * follows from the values at both ends.  With s = +-1 the side of the plane the origin lies on (s num > a_sign in every lane):
+ *   s g > t_miss    both ends on the same side, the far one by a margin: the reference's t is negative, or >= |S - P|
+ *   s g < -t_hit    the far end lies beyond the plane by a margin: 0 < t < |S - P|; the crossing point projects between the
+ *                   projections of the two ends (the rectangle test is affine too), so when the origin's own projections lie
+ *                   inside the accepted intervals (|dot(so - v0, w) - cw| < ow, same along the other edge with ck, ok: rounding
+ *                   only) and so do the sample's (|w0 + u w1 + v w2| < rw, |k0 + u k1 + v k2| < rk: rounding and the 0.001 N
+ *                   between the sample and the end of its ray), the reference accepts the hit
+ * and anything else takes the reference's arithmetic.  The margins cover 0.001 |n|, the rounding of every float involved for
+ * points within DeviceScene::cert_radius of the origin, and 1e-5 of the largest numerator (rt_build.cpp derives them).
+ * g_min / g_max: g at the light's corners; a square with s g_min > t_miss (s > 0) or g_max < -t_miss (s < 0) is missed by every
+ * sample.  All NaN for a point light: no comparison holds and nothing is decided. */
+struct DLightSq {  /* 80 B */
+    float h0, e1, e2, t_miss;
+    float g_min, g_max, a_sign, t_hit;
+    float w0, w1, w2, rw;
+    float k0, k1, k2, rk;
+    float cw, ck, ow, ok;
+};
+
 /* Object-level kd-tree node, R/src/KDTree.h:12-29, children by index, leaf refs by range. */
 struct DKdNode {  /* 32 B */
     int32_t leaf; int32_t axis; float cut; int32_t left;
@@ -109,15 +132,15 @@ struct DeviceScene {
     const DRef* refs;
     const DSphere* ref_spheres; /* kd-tree with internal nodes only: the record of reference r, stored at r (valid where */
     const DSquare* ref_squares; /* refs[r] names a sphere / a square): one fetch per object instead of two in a row   */
-    /* per (light l, square q), at [4 (l n_squares + q)]: dot(v0 - p_i, n) for the three corners p_i of a quad light that
-     * its samples are mixed from, and the distance from the square's plane (times |n|) below which a point counts as on
-     * it; NaN for a point light.  Decides per shaded point which squares no shadow ray of it can meet (shade). */
-    const float* light_sq;
+    /* per (light l, square q), at [l n_squares + q]: what decides, from the barycentric coordinates of a light sample alone,
+     * whether its shadow ray can meet the square (DLightSq; null: every ray tests every square) */
+    const DLightSq* light_sq;
     uint32_t n_spheres, n_squares, n_meshes, n_lights;
     uint32_t n_kd, n_refs;
     float box_lo[3], box_hi[3];  /* root box = Scene::computeGlobalAABB */
     float kd_epsilon;
     int32_t root_is_leaf;
+    float cert_radius; /* light_sq holds for shadow origins within this distance of the world origin (the root box lies inside) */
 };
 
 /* Inverted camera matrices, R/src/matrixUtilities.h:188-217, done once on the host in double. */
