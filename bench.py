@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--flop-per-ray", type=float, default=0.0, help="override instead of counting on the CPU (over all reference rays)")
     ap.add_argument("--flop-per-traced-ray", type=float, default=0.0, help="the same over the rays traced (discarded Phong evaluations left out)")
     ap.add_argument("--native-gather", action="store_true", help="N > 1: exchange the tiles with the library's own RCCL calls (rt_gather_tiles_device)")
+    ap.add_argument("--native-loop", action="store_true", help="every step is the library's own frame loop (rt_render_sharded_device: render, RCCL exchange and "
+                                                               "un-tile enqueued by one C call, image left on rank 0's GPU) instead of the Python harness")
     args = ap.parse_args()
 
     import torch
@@ -164,7 +166,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     api.init(local_rank)
-    if world > 1 and args.native_gather:
+    if world > 1 and (args.native_gather or args.native_loop):
         box = [api.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         api.comm_init(box[0], rank, world)
@@ -201,8 +203,20 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     image = None
 
+    d_image = torch.zeros(h * w * 3, dtype=torch.float32, device=dev) if (args.native_loop and rank == 0) else None
+    if args.native_loop and pass_spp != spp:
+        raise SystemExit("--native-loop renders a frame in one pass; this workload accumulates in passes")
+
     def step(i=None):
         nonlocal image
+        if args.native_loop:  # one C call per frame; the HIP events bracket render + exchange + un-tile
+            if i is not None:
+                ev[i][0].record(stream)
+            scene.render_sharded_device(cam, w, h, spp, args.seed, tw, th, d_image.data_ptr() if rank == 0 else 0, counters.data_ptr(), stream.cuda_stream)
+            if i is not None:
+                ev[i][1].record(stream)
+            image = d_image.view(h, w, 3) if rank == 0 else None
+            return
         out = renderer.step()  # pipelined for N > 1: returns the previous frame, flush() the last one
         image = out if out is not None else image
 
@@ -322,7 +336,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {wl.what} {w}x{h} {spp}spp" + (f" in passes of {pass_spp}" if pass_spp != spp else "") +
                                    f" bounces10 light_samples16 counter-rng seed {args.seed}",
-                       "tile": f"{tw}x{th}", "parallelism": f"tiles t%{world} per GPU + RCCL gather to rank 0" + (" (rt_gather_tiles_device)" if args.native_gather and world > 1 else ""),
+                       "tile": f"{tw}x{th}", "parallelism": f"tiles t%{world} per GPU + RCCL gather to rank 0" + (" (rt_gather_tiles_device)" if args.native_gather and world > 1 else "") + (" (library frame loop: rt_render_sharded_device)" if args.native_loop else ""),
                        "triangles": int(wl.desc.n_triangles), "scene_upload_s": round(t_build, 3),
                        "rays_traced_per_step": int(traced_total / steps), "reference_rays_per_step": int(rays_total / steps),
                        "reference_mrays_per_s": round(rays_total / dt_max / 1e6, 2),

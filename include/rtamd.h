@@ -332,7 +332,14 @@ int rt_render_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_
  * Both calls only enqueue work on hip_stream.  The library keeps the per-call device state (inverted camera,
  * tile launch order) in rings of 64 and 8 slots; a call that gets a slot whose last reader was enqueued on a
  * different stream makes its own stream wait for that reader (an event per slot), so any number of calls may be
- * in flight on any number of streams. */
+ * in flight on any number of streams.
+ * Memory and synchronisation: a render slot's workspace is allocated by the first call that uses it and grown (hipFree +
+ * hipMalloc, which wait for the device) by a call that needs more; calls of the same size afterwards only enqueue.  Without
+ * the breadth-first workers a slot holds 8 bytes per tile.  With them (scenes with kd internal nodes or a triangle BVH and a
+ * bouncing sphere, option "wide") it also holds a byte per pixel, 12 bytes x spp per listed pixel (at most a quarter of the
+ * pixels and 512 MiB) and 112 KiB of path-tree memory per worker wave (at most 4096 workers, the wave slots of the chip at
+ * four waves per SIMD: 448 MiB): up to about 0.9 GiB per slot, and a caller that changes the camera every frame cycles
+ * through all eight slots.  Blocks are kept until rt_shutdown.  rt_render_device_noalloc never allocates. */
 int rt_render_pass_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h,
                           uint32_t spp_pass, uint32_t sample0, uint32_t spp_total, uint32_t seed,
                           uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world,
@@ -380,6 +387,25 @@ int rt_comm_world(void);
 int rt_gather_tiles_device(const float* d_mine, size_t floats_per_rank, float* d_gathered, int root, void* hip_stream);
 int rt_render_sharded(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed,
                       uint32_t tile_w, uint32_t tile_h, float* rgb_image, rt_stats* stats);
+/* The frame loop behind it keeps its device buffers, a pinned host block and its events for the life of the library (a
+ * frame of the same size allocates nothing), un-tiles on the device and copies only the final row-major image to the host
+ * -- directly when rgb_image is pinned memory (hipHostMalloc / hipHostRegister), else through the pinned block.  A rank
+ * whose render fails still takes part in the exchange (its share arrives as zeros) and returns its error afterwards, so
+ * the other ranks are not left waiting.
+ * rt_render_sharded_device: the same with everything enqueued on hip_stream and nothing copied to the host: on rank 0 the
+ * row-major image is written to d_image (w * h * 3 floats of device memory; ignored elsewhere), d_counters may be null.
+ * rt_sharded_last_times: device time of the phases of the latest rt_render_sharded call on this rank (HIP events), the
+ * host-side copy out of the pinned block, and the wall time of the whole call.
+ * rt_device_count: HIP devices visible to this process (a launcher checks it before its ranks join a communicator). */
+typedef struct rt_sharded_times {
+    double render_ms, gather_ms, untile_ms, copy_ms; /* device: render kernels, RCCL exchange, tile buffers -> image, image -> host */
+    double host_copy_ms;                             /* pinned block -> rgb_image (0 when rgb_image is pinned itself) */
+    double total_ms;
+} rt_sharded_times;
+int rt_render_sharded_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed,
+                             uint32_t tile_w, uint32_t tile_h, float* d_image, uint64_t* d_counters, void* hip_stream);
+int rt_sharded_last_times(rt_sharded_times* out);
+int rt_device_count(int* n);
 
 /* ---- image output (R/main.cpp:204-216) ------------------------------------------------------
  * rt_tiles_to_rgb8_device: what rt_tiles_to_image does, on the device and fused with the reference's

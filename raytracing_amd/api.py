@@ -63,6 +63,11 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64), ("rays_skipped", C.c_uint64)]
 
 
+class ShardedTimes(C.Structure):
+    _fields_ = [("render_ms", C.c_double), ("gather_ms", C.c_double), ("untile_ms", C.c_double), ("copy_ms", C.c_double),
+                ("host_copy_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 class BuildInfo(C.Structure):
     _fields_ = [("kd_nodes", C.c_uint32), ("kd_max_depth", C.c_uint32), ("bvh_meshes", C.c_uint32), ("bvh_nodes", C.c_uint32),
                 ("bvh_max_depth", C.c_uint32), ("kernel_variant", C.c_uint32), ("device_bytes", C.c_uint64)]
@@ -81,10 +86,22 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("type", "<i4"), ("object", "<i4"), ("tri"
 # every symbol include/rtamd.h declares
 EXPORTS = ["rt_init", "rt_set_option", "rt_shutdown", "rt_last_error", "rt_scene_check", "rt_scene_create", "rt_scene_create_ex", "rt_scene_verify", "rt_scene_refit", "rt_scene_destroy", "rt_scene_kdtree",
            "rt_intersect", "rt_intersect_device", "rt_mesh_intersect", "rt_primitive_intersect", "rt_comm_unique_id", "rt_comm_init",
-           "rt_comm_destroy", "rt_comm_rank", "rt_comm_world", "rt_gather_tiles_device", "rt_render_sharded", "rt_generate_rays", "rt_trace",
+           "rt_comm_destroy", "rt_comm_rank", "rt_comm_world", "rt_gather_tiles_device", "rt_render_sharded", "rt_render_sharded_device", "rt_sharded_last_times", "rt_device_count", "rt_generate_rays", "rt_trace",
            "rt_tiles_per_rank", "rt_render", "rt_render_device", "rt_render_pass_device", "rt_render_device_noalloc", "rt_tiles_to_image", "rt_tiles_to_rgb8_device", "rt_write_ppm", "rt_counters_total", "rt_selftest_arith", "rt_normalize_dirs"]
 
 _lib = None
+
+
+def sharded_last_times():
+    t = ShardedTimes()
+    check(lib().rt_sharded_last_times(C.byref(t)))
+    return t
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().rt_device_count(C.byref(n)))
+    return n.value
 
 
 def lib():
@@ -114,6 +131,9 @@ def lib():
         L.rt_comm_init.argtypes = [vp, C.c_int, C.c_int]
         L.rt_gather_tiles_device.argtypes = [vp, C.c_size_t, vp, C.c_int, vp]
         L.rt_render_sharded.argtypes = [u64, C.POINTER(Camera)] + [u32] * 6 + [vp, C.POINTER(Stats)]
+        L.rt_render_sharded_device.argtypes = [u64, C.POINTER(Camera)] + [u32] * 6 + [vp, vp, vp]
+        L.rt_sharded_last_times.argtypes = [C.POINTER(ShardedTimes)]
+        L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.rt_generate_rays.argtypes = [C.POINTER(Camera), vp, vp, C.c_size_t, vp, vp]
         L.rt_trace.argtypes = [u64, vp, vp, C.c_size_t, vp, vp, u32, u32, vp, C.POINTER(Stats)]
         L.rt_tiles_per_rank.restype = C.c_size_t
@@ -262,6 +282,11 @@ class DeviceScene:
         st = Stats()
         check(lib().rt_render_sharded(self.h, C.byref(cam), w, h, spp, seed, tile_w, tile_h, _ptr(img), C.byref(st)))
         return img, st
+
+    def render_sharded_device(self, cam, w, h, spp, seed, tile_w, tile_h, d_image, d_counters=0, stream=0):
+        """rt_render_sharded_device: render + exchange + un-tile enqueued on `stream`; d_image: device pointer of w * h * 3 floats (rank 0)."""
+        cam = cam if isinstance(cam, Camera) else copy_struct(Camera, cam)
+        check(lib().rt_render_sharded_device(self.h, C.byref(cam), w, h, spp, seed, tile_w, tile_h, d_image, d_counters, stream))
 
     def trace(self, org, dirs, pixel, sample, seed=1, k0=2):
         org, dirs = _f32(org), _f32(dirs)

@@ -44,17 +44,16 @@ namespace {
             default: hipLaunchKernelGGL(kernel<3>, grid, dim3(256), 0, stream, __VA_ARGS__); break;     \
         }                                                                                              \
     } while (0)
-/* the same with a workgroup size chosen by the caller */
-#define RT_DISPATCH_B(mode, kernel, grid, block, stream, ...)                                                   \
+/* kernel<mode, T> with a workgroup of T threads */
+#define RT_DISPATCH_T(mode, kernel, T, grid, stream, ...)                                              \
     do {                                                                                               \
         switch (mode) {                                                                                \
-            case 0: hipLaunchKernelGGL(kernel<0>, grid, block, 0, stream, __VA_ARGS__); break;      \
-            case 1: hipLaunchKernelGGL(kernel<1>, grid, block, 0, stream, __VA_ARGS__); break;      \
-            case 2: hipLaunchKernelGGL(kernel<2>, grid, block, 0, stream, __VA_ARGS__); break;      \
-            default: hipLaunchKernelGGL(kernel<3>, grid, block, 0, stream, __VA_ARGS__); break;     \
+            case 0: hipLaunchKernelGGL((kernel<0, T>), grid, dim3(T), 0, stream, __VA_ARGS__); break;  \
+            case 1: hipLaunchKernelGGL((kernel<1, T>), grid, dim3(T), 0, stream, __VA_ARGS__); break;  \
+            case 2: hipLaunchKernelGGL((kernel<2, T>), grid, dim3(T), 0, stream, __VA_ARGS__); break;  \
+            default: hipLaunchKernelGGL((kernel<3, T>), grid, dim3(T), 0, stream, __VA_ARGS__); break; \
         }                                                                                              \
     } while (0)
-
 /* Every variant but the one for kd-trees with internal nodes exists with and without the worker code, and a launch
  * without workers takes the one without (measured: 100 k-triangle frame 36.5 -> 35.1 ms, 1 M-triangle frame 1 % faster,
  * the Cornell frame unchanged at 20.6 ms -- but 384 instead of 544 bytes of scratch per lane and a third of the spills). */
@@ -84,6 +83,7 @@ struct SceneRes {
     std::vector<std::pair<uint32_t, uint32_t>> mesh_vertices;
     float static_lo[3] = {INFINITY, INFINITY, INFINITY}, static_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool leaf_by_count = false; /* the kd root is a leaf whatever the bounds of the objects are */
+    bool broken = false;        /* a refit failed half-way: new triangles under old boxes; only rt_scene_destroy takes the handle */
 };
 
 const unsigned kCamSlots = 64;
@@ -124,13 +124,32 @@ struct Lib {
     OrderKey order_key{};
     int order_last_slot = -1;
     bool order_tiles = true;    /* RTAMD_TILE_ORDER=0 renders the tiles in index order */
+    /* rt_render_sharded: buffers that live as long as the library does (grown on demand, freed by rt_shutdown), so that a
+     * frame loop allocates nothing: this rank's tiles, the gathered tiles and the row-major image (rank 0), the counters, a
+     * pinned host block the image is copied into before it reaches the caller's (pageable) buffer, and events around the
+     * phases of the latest frame */
+    struct Sharded {
+        float* mine = nullptr; size_t mine_floats = 0;
+        float* all = nullptr; size_t all_floats = 0;
+        float* image = nullptr; size_t image_floats = 0;
+        float* pinned = nullptr; size_t pinned_floats = 0;
+        uint64_t* counters = nullptr;
+        hipEvent_t ev[5] = {}; /* start, rendered, gathered, untiled, copied */
+        rt_sharded_times last{};
+    } sh;
     std::map<rt_scene_t, SceneRes*> scenes;
     rt_scene_t next_handle = 1;
     std::string error;
 };
 Lib g;
 
-int fail(int code, const std::string& msg) { g.error = msg; return code; }
+bool g_found_broken = false; /* the latest find() met a scene a failed rt_scene_refit left inconsistent */
+int fail(int code, const std::string& msg) {
+    g.error = msg;
+    if (code == RT_E_HANDLE && g_found_broken) g.error += " (a failed rt_scene_refit left this scene inconsistent: destroy it and create it again)";
+    g_found_broken = false;
+    return code;
+}
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -158,7 +177,8 @@ void release(SceneRes* r) {
 
 SceneRes* find(rt_scene_t h) {
     auto it = g.scenes.find(h);
-    return it == g.scenes.end() ? nullptr : it->second;
+    g_found_broken = it != g.scenes.end() && it->second->broken;
+    return (it == g.scenes.end() || it->second->broken) ? nullptr : it->second;
 }
 
 /* device temporaries of the host-pointer entry points */
@@ -377,6 +397,10 @@ int rt_shutdown(void) {
     for (unsigned i = 0; i < kCamSlots; ++i) if (g.cam_done[i]) { (void)hipEventDestroy(g.cam_done[i]); g.cam_done[i] = nullptr; }
     for (unsigned i = 0; i < kOrderSlots; ++i) if (g.order_done[i]) { (void)hipEventDestroy(g.order_done[i]); g.order_done[i] = nullptr; }
     g.scratch_ptr = nullptr;
+    (void)hipFree(g.sh.mine); (void)hipFree(g.sh.all); (void)hipFree(g.sh.image); (void)hipFree(g.sh.counters);
+    if (g.sh.pinned) (void)hipHostFree(g.sh.pinned);
+    for (hipEvent_t& e : g.sh.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    g.sh = Lib::Sharded();
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
@@ -554,6 +578,7 @@ int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times
 }
 
 int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normals, uint32_t n_vertices, float* device_ms) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_scene_refit: call rt_init first");
     SceneRes* r = find(scene);
     if (!r) return fail(RT_E_HANDLE, "rt_scene_refit: unknown scene");
     if (!positions || !normals) return fail(RT_E_INVALID, "rt_scene_refit: null argument");
@@ -573,6 +598,9 @@ int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normal
     for (size_t k = 0; k < 2 * n_mesh; ++k) rtd::box_init(&boxes[8 * k]);
     HIP_TRY(hipEventRecord(g.ev0, g.stream));
     HIP_TRY(hipMemcpyAsync(d_pos, positions, (size_t)n_vertices * 12, hipMemcpyHostToDevice, g.stream));
+    /* From here on the scene's tables are overwritten in place.  An error return before the end leaves new triangles under
+     * old boxes, which later queries would silently miss: the handle is then marked and refused until it is destroyed. */
+    struct Guard { SceneRes* r; bool done; ~Guard() { if (!done) r->broken = true; } } guard{r, false};
     HIP_TRY(hipMemcpyAsync(const_cast<float*>(r->dev.normals), normals, (size_t)n_vertices * 12, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(d_box, boxes.data(), n_mesh * 64, hipMemcpyHostToDevice, g.stream));
     for (size_t k = 0; k < n_mesh; ++k) {
@@ -620,6 +648,7 @@ int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normal
         if (!(std::sqrt(3.0f) * far + 0.002f <= r->dev.cert_radius)) r->dev.light_sq = nullptr;
     }
     g.order_last_slot = -1; /* a launch order or deep list probed before the vertices moved is not used again */
+    guard.done = true;
     return RT_OK;
 }
 
@@ -942,7 +971,8 @@ static int render_pass(bool static_mem, rt_scene_t scene, const rt_camera* cam, 
         if (fresh) {
             /* one thread per pixel of the tile: a tile of at most 64 pixels is probed by a single wave (with 256 threads three
              * of four waves of every workgroup would only wait at its barriers and hold wave slots: 0.20 -> 0.07 ms per frame) */
-            RT_DISPATCH_B(r->mode, k_tile_class, dim3(rp.n_local_tiles), dim3(tile_w * tile_h <= 64u ? 64 : 256), st, r->dev, (const DCamera*)d_cam, rp, ws, dl);
+            if (tile_w * tile_h <= 64u) RT_DISPATCH_T(r->mode, k_tile_class, 64, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws, dl);
+            else RT_DISPATCH_T(r->mode, k_tile_class, 256, dim3(rp.n_local_tiles), st, r->dev, (const DCamera*)d_cam, rp, ws, dl);
             if (want_order) hipLaunchKernelGGL(k_tile_place, dim3(1), dim3(1024), 0, st, ws, rp.n_local_tiles);
             HIP_TRY(hipGetLastError());
         }
@@ -1056,47 +1086,135 @@ int rt_gather_tiles_device(const float* d_mine, size_t floats_per_rank, float* d
     return RT_OK;
 }
 
+/* grows one of the sharded-render buffers; only a growing call allocates (and then waits for the device) */
+static int grow_device(float** p, size_t* have, size_t want) {
+    if (*have >= want && *p) return RT_OK;
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc((void**)p, (want ? want : 1) * sizeof(float)));
+    *have = want;
+    return RT_OK;
+}
+
+/* Render + gather + un-tile, all enqueued on `st`.  On rank 0 the row-major image ends up in d_image (w * h * 3 floats, a
+ * device pointer of the caller, or the library's own when null); d_counters may be null.  A rank whose render cannot be
+ * enqueued still takes part in the exchange (its share arrives as zeros) and reports the error afterwards, so that one
+ * failing rank does not leave the others waiting in the collective. */
+static int sharded_enqueue(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
+                           uint32_t tile_h, float* d_image, uint64_t* d_counters, hipStream_t st, bool timed) {
+    const int rank = rtc::rank(), world = rtc::world(); /* 0 / 1 without a communicator */
+    if (!w || !h || !spp || !tile_w || !tile_h) return fail(RT_E_INVALID, "rt_render_sharded: zero size");
+    if ((uint64_t)w * h > 0x7fffffffull / 3) return fail(RT_E_LIMIT, "rt_render_sharded: image too large");
+    /* every rank's buffer has the size of rank 0's, the largest: the gathered block is regular */
+    const size_t per_rank_tiles = rt_tiles_per_rank(w, h, tile_w, tile_h, 0, (uint32_t)world);
+    const size_t per_rank = per_rank_tiles * tile_w * tile_h * 3;
+    if (per_rank == 0) return fail(RT_E_INVALID, "rt_render_sharded: zero size");
+    Lib::Sharded& sh = g.sh;
+    int rc;
+    if ((rc = grow_device(&sh.mine, &sh.mine_floats, per_rank))) return rc;
+    if (rank == 0 && world > 1 && (rc = grow_device(&sh.all, &sh.all_floats, per_rank * (size_t)world))) return rc;
+    if (rank == 0 && !d_image) {
+        if ((rc = grow_device(&sh.image, &sh.image_floats, (size_t)w * h * 3))) return rc;
+        d_image = sh.image;
+    }
+    for (hipEvent_t& e : sh.ev) if (!e) HIP_TRY(hipEventCreate(&e));
+    if (timed) HIP_TRY(hipEventRecord(sh.ev[0], st));
+    /* the padding tiles of a rank with fewer tiles than rank 0 are never written by the render: keep them defined */
+    const size_t own_floats = rt_tiles_per_rank(w, h, tile_w, tile_h, (uint32_t)rank, (uint32_t)world) * tile_w * tile_h * 3;
+    if (own_floats < per_rank) HIP_TRY(hipMemsetAsync(sh.mine + own_floats, 0, (per_rank - own_floats) * 4, st));
+    int rc_render = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, (uint32_t)rank, (uint32_t)world, sh.mine, d_counters, st);
+    std::string render_err;
+    if (rc_render) { render_err = g.error; (void)hipMemsetAsync(sh.mine, 0, per_rank * 4, st); }
+    if (timed) HIP_TRY(hipEventRecord(sh.ev[1], st));
+    if (world > 1) {
+        std::string err;
+        if (!rtc::gather(sh.mine, per_rank, sh.all, 0, st, err)) return fail(RT_E_HIP, "rt_render_sharded: " + err);
+    }
+    if (timed) HIP_TRY(hipEventRecord(sh.ev[2], st));
+    if (rank == 0) {
+        const uint32_t tiles_x = (w + tile_w - 1) / tile_w;
+        hipLaunchKernelGGL(k_tiles_to_image, dim3(blocks_for(3 * (size_t)w * h)), dim3(256), 0, st, world > 1 ? sh.all : sh.mine, w, h, tile_w, tile_h,
+                           tiles_x, (uint32_t)world, (uint32_t)per_rank_tiles, d_image);
+        HIP_TRY(hipGetLastError());
+    }
+    if (timed) HIP_TRY(hipEventRecord(sh.ev[3], st));
+    if (rc_render) return fail(rc_render, render_err);
+    return RT_OK;
+}
+
+int rt_render_sharded_device(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w,
+                             uint32_t tile_h, float* d_image, uint64_t* d_counters, void* hip_stream) {
+    if (!g.ready) return fail(RT_E_NOINIT, "rt_render_sharded_device: call rt_init first");
+    if (rtc::rank() == 0 && !d_image) return fail(RT_E_INVALID, "rt_render_sharded_device: rank 0 needs the image buffer");
+    HIP_TRY(hipSetDevice(g.device));
+    return sharded_enqueue(scene, cam, w, h, spp, seed, tile_w, tile_h, d_image, d_counters, (hipStream_t)hip_stream, false);
+}
+
 int rt_render_sharded(rt_scene_t scene, const rt_camera* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t seed, uint32_t tile_w, uint32_t tile_h,
                       float* rgb_image, rt_stats* stats) {
     if (!g.ready) return fail(RT_E_NOINIT, "rt_render_sharded: call rt_init first");
-    const int rank = rtc::rank(), world = rtc::world(); /* 0 / 1 without a communicator */
+    const int rank = rtc::rank();
     if (rank == 0 && !rgb_image) return fail(RT_E_INVALID, "rt_render_sharded: rank 0 needs the image buffer");
     if (stats) std::memset(stats, 0, sizeof(*stats));
     HIP_TRY(hipSetDevice(g.device));
-    /* every rank's buffer has the size of rank 0's, the largest: the gathered block is regular */
-    const size_t per_rank = rt_tiles_per_rank(w, h, tile_w, tile_h, 0, (uint32_t)world) * tile_w * tile_h * 3;
-    if (per_rank == 0) return fail(RT_E_INVALID, "rt_render_sharded: zero size");
-    Scratch tmp;
-    void *d_mine, *d_all = nullptr, *d_cnt;
-    int rc;
-    if ((rc = tmp.get(&d_mine, per_rank * 4)) || (rc = tmp.get(&d_cnt, RT_COUNTER_WORDS * 8))) return rc;
-    if (rank == 0 && (rc = tmp.get(&d_all, per_rank * 4 * (size_t)world))) return rc;
-    HIP_TRY(hipMemsetAsync(d_mine, 0, per_rank * 4, g.stream));
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, RT_COUNTER_WORDS * 8, g.stream));
-    HIP_TRY(hipEventRecord(g.ev0, g.stream));
-    if ((rc = rt_render_device(scene, cam, w, h, spp, seed, tile_w, tile_h, (uint32_t)rank, (uint32_t)world, (float*)d_mine, (uint64_t*)d_cnt, g.stream))) return rc;
-    HIP_TRY(hipEventRecord(g.ev1, g.stream));
-    if (world > 1) {
-        std::string err;
-        if (!rtc::gather((const float*)d_mine, per_rank, (float*)d_all, 0, g.stream, err)) return fail(RT_E_HIP, "rt_render_sharded: " + err);
-    }
-    std::vector<uint64_t> slots(RT_COUNTER_WORDS);
-    HIP_TRY(hipMemcpyAsync(slots.data(), d_cnt, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, g.stream));
-    std::vector<float> gathered;
+    Lib::Sharded& sh = g.sh;
+    if (!sh.counters) HIP_TRY(hipMalloc((void**)&sh.counters, RT_COUNTER_WORDS * 8));
+    HIP_TRY(hipMemsetAsync(sh.counters, 0, RT_COUNTER_WORDS * 8, g.stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = sharded_enqueue(scene, cam, w, h, spp, seed, tile_w, tile_h, nullptr, sh.counters, g.stream, true);
+    if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
+    const size_t image_floats = (size_t)w * h * 3;
+    double host_ms = 0.0;
     if (rank == 0) {
-        gathered.resize(per_rank * (size_t)world);
-        HIP_TRY(hipMemcpyAsync(gathered.data(), world > 1 ? d_all : d_mine, gathered.size() * 4, hipMemcpyDeviceToHost, g.stream));
+        /* device -> host: straight into the caller's buffer when it is pinned, else through the library's pinned block (a copy
+         * into pageable memory is staged by the runtime in small pieces at a fraction of the link's rate) */
+        hipPointerAttribute_t attr;
+        const bool pinned = hipPointerGetAttributes(&attr, rgb_image) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError(); /* an ordinary malloc'ed pointer makes the query fail: not an error of this call */
+        if (pinned) HIP_TRY(hipMemcpyAsync(rgb_image, sh.image, image_floats * 4, hipMemcpyDeviceToHost, g.stream));
+        else {
+            if (sh.pinned_floats < image_floats) {
+                if (sh.pinned) { HIP_TRY(hipHostFree(sh.pinned)); sh.pinned = nullptr; sh.pinned_floats = 0; }
+                HIP_TRY(hipHostMalloc((void**)&sh.pinned, image_floats * 4, hipHostMallocDefault));
+                sh.pinned_floats = image_floats;
+            }
+            HIP_TRY(hipMemcpyAsync(sh.pinned, sh.image, image_floats * 4, hipMemcpyDeviceToHost, g.stream));
+        }
+        HIP_TRY(hipEventRecord(sh.ev[4], g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (!pinned) {
+            const auto h0 = std::chrono::steady_clock::now();
+            std::memcpy(rgb_image, sh.pinned, image_floats * 4);
+            host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+        }
+    } else {
+        HIP_TRY(hipEventRecord(sh.ev[4], g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
     }
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    if (rank == 0 && (rc = rt_tiles_to_image(gathered.data(), w, h, tile_w, tile_h, (uint32_t)world, rgb_image))) return rc;
+    uint64_t slots[RT_COUNTER_WORDS];
+    HIP_TRY(hipMemcpy(slots, sh.counters, RT_COUNTER_WORDS * 8, hipMemcpyDeviceToHost));
+    float ms[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], sh.ev[k], sh.ev[k + 1]));
+    sh.last.render_ms = ms[0]; sh.last.gather_ms = ms[1]; sh.last.untile_ms = ms[2]; sh.last.copy_ms = ms[3]; sh.last.host_copy_ms = host_ms;
+    sh.last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats) { /* this rank's share */
         uint64_t cnt[RT_COUNTER_FIELDS];
-        rt_counters_total(slots.data(), cnt);
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
-        stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms;
+        rt_counters_total(slots, cnt);
+        stats->rays = cnt[0]; stats->samples = cnt[1]; stats->nodes = cnt[2]; stats->kernel_ms = ms[0];
         stats->bvh_nodes = cnt[3]; stats->bvh_tris = cnt[4]; stats->rays_skipped = cnt[5];
     }
+    return RT_OK;
+}
+
+int rt_sharded_last_times(rt_sharded_times* out) {
+    if (!out) return fail(RT_E_INVALID, "rt_sharded_last_times: null output");
+    *out = g.sh.last;
+    return RT_OK;
+}
+
+int rt_device_count(int* n) {
+    if (!n) return fail(RT_E_INVALID, "rt_device_count: null output");
+    *n = 0;
+    HIP_TRY(hipGetDeviceCount(n));
     return RT_OK;
 }
 

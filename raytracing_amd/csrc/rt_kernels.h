@@ -152,13 +152,13 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
  * the output layout depend on the tile id alone.
  * Workspace (uint32): [0, n) key of local tile i (0 = deepest), [n, 2n) the order. */
 #define RT_ORDER_KEYS (RT_PROBE_CAP + 1)
-template <int M>
-__global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws, DeepList dl) {
+template <int M, int T = 256> /* T: threads of the workgroup, 64 for tiles of at most 64 pixels; the traversal stack in LDS is sized by it */
+__global__ __launch_bounds__(T) void k_tile_class(DeviceScene sc, const DCamera* __restrict__ cam, RenderParams rp, uint32_t* __restrict__ ws, DeepList dl) {
     /* The probe only has to say where path trees are deep, which the spheres decide.  In a scene whose root is a leaf
      * it therefore leaves the meshes out: no BVH is traversed, and a 10 M-triangle scene is probed as fast as the bare box. */
     constexpr int P = (M == RT_M_BVH) ? 0 : M;
     if (M == RT_M_BVH) sc.n_meshes = 0;
-    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
+    __shared__ uint32_t s_stack[RT_STACK_LDS * T];
     __shared__ uint32_t s_deepest, s_bounces;
     const uint32_t local_tile = blockIdx.x; /* one workgroup per tile, one thread per pixel (a 16 x 16 tile) */
     const uint32_t tile = rp.rank + local_tile * rp.world;
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
         float v = ((float)(int)y + fy) / (float)(int)rp.h;
         f3 o, d;
         primary_ray(*cam, u, v, o, d);
-        Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE);
+        Cnt cnt = new_cnt(s_stack + threadIdx.x, T);
         Rng rng; rng.key = 0; rng.k = 0;
         (void)trace_path<P, true>(sc, o, norm3(d), rng, cnt);
         return cnt.nodes;
     };
     uint32_t deepest = 0;
-    for (uint32_t i = threadIdx.x; i < px_per_tile; i += 256) { /* the centre of every pixel */
+    for (uint32_t i = threadIdx.x; i < px_per_tile; i += T) { /* the centre of every pixel */
         const uint32_t x = x0 + i % rp.tile_w, y = y0 + i / rp.tile_w;
         uint32_t nodes = 0;
         if (x < rp.w && y < rp.h) nodes = probe(x, y, 0.5f, 0.5f);
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_tile_class(DeviceScene sc, const DCamer
     /* Deep list.  A tile some of whose pixels look at a mirror or glass sphere also probes the corners of its pixels: the
      * samples of a pixel on the rim of a sphere differ, and one deep sample makes the pixel's wave a long one. */
     const bool corners = s_bounces != 0u; /* the same for the whole workgroup */
-    for (uint32_t i0 = 0; i0 < px_per_tile; i0 += 256) { /* every thread of the workgroup makes every trip */
+    for (uint32_t i0 = 0; i0 < px_per_tile; i0 += T) { /* every thread of the workgroup makes every trip */
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t x = x0 + i % rp.tile_w, y = y0 + i / rp.tile_w;
         const bool valid = i < px_per_tile && x < rp.w && y < rp.h;
@@ -683,6 +683,21 @@ __global__ __launch_bounds__(256) void k_tiles_to_rgb8(const float* __restrict__
     const uint64_t px = ((uint64_t)(t % world) * per_rank + t / world) * tile_w * tile_h + (uint64_t)(y % tile_h) * tile_w + x % tile_w;
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[3 * i + c] = (uint8_t)(int)(255.f * min_std(1.f, tiles[3 * px + c]));
+}
+
+/* the same pixel lookup without the quantisation: rank-major tile buffers -> the row-major float image of R/main.cpp:191.
+ * One thread per float: consecutive threads write consecutive words. */
+__global__ __launch_bounds__(256) void k_tiles_to_image(const float* __restrict__ tiles, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h,
+                                                        uint32_t tiles_x, uint32_t world, uint32_t per_rank, float* __restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= 3ull * w * h) return;
+    const uint64_t i = j / 3u;
+    const uint32_t c = (uint32_t)(j - 3u * i);
+    const uint32_t x = (uint32_t)(i % w), y = (uint32_t)(i / w);
+    const uint32_t ty = y / tile_h, tx = x / tile_w;
+    const uint32_t t = ty * tiles_x + (tx + tiles_x - ty % tiles_x) % tiles_x; /* inverse of rt_tile_column */
+    const uint64_t px = ((uint64_t)(t % world) * per_rank + t / world) * tile_w * tile_h + (uint64_t)(y % tile_h) * tile_w + x % tile_w;
+    out[j] = tiles[3 * px + c];
 }
 
 RT_DEV rt_hit pack_hit(const FullHit& h, int type, int object, int tri, float u, float v) {

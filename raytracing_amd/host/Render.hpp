@@ -56,5 +56,9 @@ inline void ray_trace_from_camera(Scene& scene, Camera& camera, unsigned nsample
     auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count();
     std::cout << "Image saved to '" << filename << "' in " << ms << " ms." << std::endl;
     std::cout << st.rays << " rays, kernel " << st.kernel_ms << " ms (" << (st.kernel_ms > 0 ? st.rays / st.kernel_ms / 1e3 : 0.0) << " Mrays/s)" << std::endl;
+    rt_sharded_times tm{};
+    if (rt_sharded_last_times(&tm) == RT_OK)
+        std::cout << "frame on rank 0 of " << rt_comm_world() << ": render " << tm.render_ms << " ms, gather " << tm.gather_ms << " ms, un-tile " << tm.untile_ms
+                  << " ms, copy to host " << tm.copy_ms << " + " << tm.host_copy_ms << " ms, call " << tm.total_ms << " ms" << std::endl;
     if (stats_out) *stats_out = st;
 }

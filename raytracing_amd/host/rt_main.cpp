@@ -9,6 +9,7 @@
  *        binary P6; --gpus N: N processes, one per GPU (devices 0 .. N-1), each renders the tiles t % N == its rank and
  *        rank 0 gathers them over RCCL and writes the file.
  * e.g.  rt_main --keys +r   renders scene 3 (Cornell box + mesh) like the committed rendu.ppm. */
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -63,6 +64,7 @@ int main(int argc, char** argv) {
     if (gpus > 1) {
         /* one process per GPU, forked before anything has touched a GPU; the parent only waits for them */
         const std::string id_file = "/tmp/rtamd_comm_" + std::to_string((long)getpid());
+        std::remove(id_file.c_str()); /* a file left by an earlier run with this process id would be read as a valid id */
         std::vector<pid_t> kids;
         bool child = false;
         for (unsigned r = 0; r < gpus && !child; ++r) {
@@ -72,13 +74,28 @@ int main(int argc, char** argv) {
             else kids.push_back(pid);
         }
         if (!child) {
+            /* the first rank that fails ends the run: its peers may already wait for it inside the communicator's set-up or
+             * an exchange, where nothing would ever wake them */
             int worst = EXIT_SUCCESS;
-            for (pid_t pid : kids) {
+            size_t left = kids.size();
+            while (left > 0) {
                 int status = 0;
-                if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) worst = EXIT_FAILURE;
+                const pid_t pid = waitpid(-1, &status, 0);
+                if (pid < 0) { worst = EXIT_FAILURE; break; }
+                --left;
+                for (pid_t& k : kids) if (k == pid) k = 0;
+                if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+                    worst = EXIT_FAILURE;
+                    for (pid_t k : kids) if (k > 0) kill(k, SIGTERM);
+                }
             }
             std::remove(id_file.c_str());
             return worst;
+        }
+        int n_devices = 0;
+        if (rt_device_count(&n_devices) != RT_OK || (unsigned)n_devices < gpus) {
+            std::cerr << "rank " << rank << ": --gpus " << gpus << " but " << n_devices << " HIP device(s) visible" << std::endl;
+            return EXIT_FAILURE; /* before anybody waits for this rank */
         }
         setenv("RT_DEVICE", std::to_string(rank).c_str(), 1);
         rthost::ensure_device();

@@ -101,6 +101,52 @@ def test_primitive_intersect_and_sharded_render_of_one_rank():
     g.close()
 
 
+def test_native_frame_loop_costs_and_device_image():
+    """The library's own multi-GPU frame loop at one rank on the headline frame (Cornell 1080p, 64 spp): rt_render_sharded and
+    rt_render_sharded_device give the image of rt_render bit for bit; a second frame of the same size allocates nothing and
+    costs little more than its kernels -- device-side un-tile, one copy of the final image (the phases are printed)."""
+    import torch
+    from raytracing_amd import api, workloads
+    api.init(0)
+    wl = workloads.make("c2")
+    g = wl.upload()
+    cam, w, h, spp = wl.camera(), wl.w, wl.h, wl.spp
+    want, st = g.render(cam, w, h, spp, seed=1, tile_w=8, tile_h=8)
+    got, _ = g.render_sharded(cam, w, h, spp, seed=1, tile_w=8, tile_h=8)          # first frame: buffers are made
+    assert got.tobytes() == want.tobytes()
+    pinned = torch.empty((h, w, 3), dtype=torch.float32, pin_memory=True)           # the caller's buffer is pinned: copied straight into it
+    stats = api.Stats()
+    c = cam if isinstance(cam, api.Camera) else api.copy_struct(api.Camera, cam)
+    import ctypes as C
+    for _ in range(2):
+        api.check(api.lib().rt_render_sharded(g.h, C.byref(c), w, h, spp, 1, 8, 8, pinned.data_ptr(), C.byref(stats)))
+    t = api.sharded_last_times()
+    assert pinned.numpy().tobytes() == want.tobytes() and stats.rays == st.rays
+    mb = w * h * 12 / 1e6
+    print(f"rt_render_sharded, world 1, {w}x{h} {spp} spp into pinned memory: render {t.render_ms:.3f} ms, gather {t.gather_ms:.3f}, un-tile {t.untile_ms:.3f}, "
+          f"copy {t.copy_ms:.3f} ms ({mb / t.copy_ms:.1f} GB/s), host copy {t.host_copy_ms:.3f}, whole call {t.total_ms:.3f} ms")
+    assert t.host_copy_ms == 0.0 and mb / t.copy_ms >= 20.0, "the image leaves the device in one copy at the link's rate"
+    assert t.total_ms <= t.render_ms + 1.5 + t.copy_ms, "fixed cost of a frame beyond its kernels and the copy"
+    got2, _ = g.render_sharded(cam, w, h, spp, seed=1, tile_w=8, tile_h=8)          # pageable destination: through the pinned block
+    t2 = api.sharded_last_times()
+    print(f"... into pageable memory: copy {t2.copy_ms:.3f} + host copy {t2.host_copy_ms:.3f} ms, whole call {t2.total_ms:.3f} ms")
+    assert got2.tobytes() == want.tobytes()
+    d_img = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    g.render_sharded_device(cam, w, h, spp, 1, 8, 8, d_img.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d_img.cpu().numpy().tobytes() == want.tobytes()
+    g.close()
+
+
+def test_launcher_refuses_more_ranks_than_gpus(tmp_path):
+    """rt_main --gpus N with fewer visible GPUs ends with an error instead of leaving ranks waiting for one another."""
+    from raytracing_amd import api
+    n = api.device_count()
+    r = subprocess.run([os.path.join(HOST_DIR, "rt_main"), "--w", "64", "--h", "48", "--spp", "2", "--gpus", str(n + 1), "--out", str(tmp_path / "x.ppm"),
+                        "--off", host.STAR_OFF], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"HIP device" in r.stderr
+
+
 def test_headless_plus_and_r_keys(tmp_path):
     """rt_main --keys +r : '+' selects scene 3, 'r' renders it to a P3 file; same bytes as the oracle's render
     of that scene under the counter RNG (up to the rare pixel whose colour sits on a quantisation step)."""

@@ -128,6 +128,61 @@ def test_trace_per_sample_colors(scene_pair):
     assert np.abs(oc - gc).max() <= COLOR_ATOL, np.abs(oc - gc).max()
 
 
+def _moved_cornell(scale, shift):
+    """The built-in Cornell box (scene 2) scaled about the origin and translated: descriptor arrays of its own."""
+    base = orc.Scene.builtin(2)
+    d = api.copy_struct(api.SceneDesc, base.desc)
+    shift = np.asarray(shift, np.float32)
+    mv = lambda p: (np.asarray(list(p), np.float32) * np.float32(scale) + shift).astype(np.float32)
+    spheres = (api.Sphere * d.n_spheres)()
+    for i in range(d.n_spheres):
+        spheres[i].center[:] = mv(d.spheres[i].center)
+        spheres[i].radius = float(np.float32(d.spheres[i].radius) * np.float32(scale))
+        spheres[i].material = d.spheres[i].material
+    squares = (api.Square * d.n_squares)()
+    for i in range(d.n_squares):
+        for v in range(4):
+            squares[i].v[v][:] = mv(d.squares[i].v[v])
+        squares[i].material = d.squares[i].material
+    lights = (api.Light * d.n_lights)()
+    for i in range(d.n_lights):
+        lights[i].type = d.lights[i].type
+        lights[i].color[:] = list(d.lights[i].color)
+        for name in ("pos", "p0", "p1", "p2"):
+            getattr(lights[i], name)[:] = mv(getattr(d.lights[i], name))
+    d.spheres, d.squares, d.lights = spheres, squares, lights
+    return d, [base, spheres, squares, lights]
+
+
+@pytest.mark.parametrize("scale,shift", [(137.0, (310.0, -220.0, 170.0)), (0.01, (0.0, 0.0, 0.0)), (1.0, (-2000.0, 1500.0, 900.0))])
+def test_shadow_rules_hold_at_other_scales(scale, shift):
+    """The rules that decide shadow rays without the objects' own arithmetic (light / square table, sphere certificates) carry
+    margins derived from the magnitudes of the scene: a Cornell box 137 times as large and far from the origin, one a hundred
+    times smaller, and one 2 500 units away must still agree with the oracle ray for ray (equal ray and node counts) and colour
+    for colour."""
+    d, keep = _moved_cornell(scale, shift)
+    o = orc.Scene.from_desc(api.copy_struct(orc.SceneDesc, d), keep=keep)
+    g = api.DeviceScene(d, keep=keep)
+    w, h, spp = 48, 40, 4
+    rng = np.random.default_rng(31)
+    ys, xs = np.mgrid[0:h, 0:w]
+    pix = np.repeat((xs + ys * w).ravel().astype(np.uint32), spp)
+    smp = np.tile(np.arange(spp, dtype=np.uint32), w * h)
+    u = ((np.repeat(xs.ravel(), spp) + rng.random(pix.size)) / w).astype(np.float32)
+    v = ((np.repeat(ys.ravel(), spp) + rng.random(pix.size)) / h).astype(np.float32)
+    org, dirs = orc.generate_rays(orc.camera_default(w, h), u, v)
+    org = (org * np.float32(scale) + np.asarray(shift, np.float32)).astype(np.float32)
+    dirs = orc.normalize_dirs(dirs)
+    oc, ost = o.trace(org, dirs, pix, smp, seed=1, k0=2)
+    gc, gst = g.trace(org, dirs, pix, smp, seed=1, k0=2)
+    assert ost.nodes > 2 * pix.size // 3, "the rays must reach the box"
+    assert (ost.rays, ost.samples, ost.nodes) == (gst.rays, gst.samples, gst.nodes)
+    assert np.abs(oc - gc).max() <= COLOR_ATOL, np.abs(oc - gc).max()
+    a, b = o.intersect(org, dirs), g.intersect(org, dirs)
+    assert a.tobytes() == b.tobytes()
+    g.close()
+
+
 def psnr(a, b):
     mse = np.mean((np.clip(a, 0, 1).astype(np.float64) - np.clip(b, 0, 1)) ** 2)
     return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
