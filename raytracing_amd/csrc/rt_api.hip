@@ -301,6 +301,12 @@ int bvh4_on_device(SceneRes* r) {
     r->allocs.push_back(nodes);
     r->dev.bvh4 = nodes;
     r->n_bvh4 = n4;
+    DBvh4Q* qnodes = nullptr;
+    HIP_TRY(hipMalloc((void**)&qnodes, (size_t)(n4 ? n4 : 1) * sizeof(DBvh4Q)));
+    r->allocs.push_back(qnodes);
+    r->dev.bvh4q = qnodes;
+    HIP_TRY(rtd::quantise_bvh4(nodes, n4, qnodes, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
     for (size_t k = 0; k < owner.size(); ++k) r->host.meshes[owner[k]].bvh4_root = roots4[k];
     return RT_OK;
 }
@@ -560,6 +566,9 @@ int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times
     std::vector<DBvh4Node> wide(r->n_bvh4); /* and the four-wide trees the rays actually walk */
     if (r->n_bvh4) HIP_TRY(hipMemcpy(wide.data(), r->dev.bvh4, r->n_bvh4 * sizeof(DBvh4Node), hipMemcpyDeviceToHost));
     if (!rtb::verify_bvh4(b, wide, stack4, err)) return fail(RT_E_LIMIT, err);
+    std::vector<DBvh4Q> quant(r->n_bvh4); /* ... in the 64-byte form they are fetched in */
+    if (r->n_bvh4) HIP_TRY(hipMemcpy(quant.data(), r->dev.bvh4q, r->n_bvh4 * sizeof(DBvh4Q), hipMemcpyDeviceToHost));
+    if (!rtb::verify_bvh4q(wide, quant, err)) return fail(RT_E_LIMIT, err);
     if (info) {
         std::memset(info, 0, sizeof(*info));
         int kd_depth = 0;
@@ -569,7 +578,7 @@ int rt_scene_verify(rt_scene_t scene, rt_build_info* info, rt_build_times* times
         info->bvh_nodes = (uint32_t)r->n_bvh; info->bvh_max_depth = (uint32_t)depth;
         info->kernel_variant = (uint32_t)r->mode;
         info->device_bytes = r->host.spheres.size() * sizeof(DSphere) + r->host.squares.size() * sizeof(DSquare) + b.meshes.size() * sizeof(DMesh) +
-                             r->n_tris * (sizeof(DTri) + 4) + r->n_bvh * sizeof(DBvhNode) + r->n_bvh4 * sizeof(DBvh4Node) + (size_t)r->n_normals * 4 +
+                             r->n_tris * (sizeof(DTri) + 4) + r->n_bvh * sizeof(DBvhNode) + r->n_bvh4 * (sizeof(DBvh4Node) + sizeof(DBvh4Q)) + (size_t)r->n_normals * 4 +
                              r->host.materials.size() * sizeof(DMaterial) + r->host.lights.size() * sizeof(DLight) +
                              r->host.kd.size() * sizeof(DKdNode) + r->host.refs.size() * sizeof(DRef);
     }
@@ -636,6 +645,7 @@ int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normal
         e = rtd::collapse_to_bvh4(r->dev.bvh, (uint32_t)r->n_bvh, roots.data(), (uint32_t)roots.size(), g.stream, &same, &n4, roots4.data(), err,
                                   const_cast<DBvh4Node*>(r->dev.bvh4), (uint32_t)r->n_bvh4);
         if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_refit: " + err);
+        HIP_TRY(rtd::quantise_bvh4(r->dev.bvh4, (uint32_t)r->n_bvh4, const_cast<DBvh4Q*>(r->dev.bvh4q), g.stream));
     }
     HIP_TRY(hipMemcpyAsync(const_cast<DMesh*>(r->dev.meshes), r->host.meshes.data(), n_mesh * sizeof(DMesh), hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipEventRecord(g.ev1, g.stream));

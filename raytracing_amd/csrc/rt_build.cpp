@@ -447,6 +447,30 @@ bool verify_bvh4(const Built& b, const std::vector<DBvh4Node>& bvh4, int& max_st
     return true;
 }
 
+bool verify_bvh4q(const std::vector<DBvh4Node>& bvh4, const std::vector<DBvh4Q>& quant, std::string& err) {
+    if (bvh4.size() != quant.size()) return fail(err, "bvh4q: table sizes differ");
+    for (size_t i = 0; i < bvh4.size(); ++i) {
+        const DBvh4Node& n = bvh4[i];
+        const DBvh4Q& q = quant[i];
+        const float* lo[4] = {n.half[0].lo0, n.half[0].lo1, n.half[1].lo0, n.half[1].lo1};
+        const float* hi[4] = {n.half[0].hi0, n.half[0].hi1, n.half[1].hi0, n.half[1].hi1};
+        const int32_t c[4] = {n.half[0].c0, n.half[0].c1, n.half[1].c0, n.half[1].c1};
+        const int32_t cnt[4] = {n.half[0].n0, n.half[0].n1, n.half[1].n0, n.half[1].n1};
+        for (int k = 0; k < 4; ++k) {
+            const bool empty = cnt[k] == 0 && c[k] < 0;
+            const int32_t want = empty ? RT_BVH4Q_EMPTY : (cnt[k] > 0 ? ~(c[k] * 8 + cnt[k]) : c[k]);
+            if (q.child[k] != want) return fail(err, "bvh4q: child code differs from the full-precision node");
+            if (empty) continue;
+            for (int a = 0; a < 3; ++a) {
+                const float ql = (float)((q.q[a] >> (8 * k)) & 255u), qh = (float)((q.q[3 + a] >> (8 * k)) & 255u);
+                const float dlo = std::fmaf(ql, q.scale[a], q.lo[a]), dhi = std::fmaf(qh, q.scale[a], q.lo[a]);
+                if (!(dlo <= lo[k][a]) || !(dhi >= hi[k][a])) return fail(err, "bvh4q: a quantised child box does not enclose the original");
+            }
+        }
+    }
+    return true;
+}
+
 bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defer_meshes) {
     out = Built();
     if ((d.n_spheres && !d.spheres) || (d.n_squares && !d.squares) || (d.n_meshes && !d.meshes) ||

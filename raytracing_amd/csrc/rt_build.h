@@ -46,6 +46,9 @@ bool verify_bvh(const Built& b, int& max_depth, std::string& err);
 /* The same walk over the four-wide trees the rays traverse (b.meshes[].bvh4_root into bvh4): every triangle of a BVH mesh in
  * exactly one leaf, boxes nested and enclosing their triangles; max_stack = the most entries a traversal can have pending. */
 bool verify_bvh4(const Built& b, const std::vector<DBvh4Node>& bvh4, int& max_stack, std::string& err);
+/* The quantised nodes against the full-precision ones they were made from: same children in the same slots, and every decoded
+ * child box (fmaf(q, scale, lo), the traversal's expression) encloses the original one. */
+bool verify_bvh4q(const std::vector<DBvh4Node>& bvh4, const std::vector<DBvh4Q>& quant, std::string& err);
 bool invert_camera(const rt_camera& cam, DCamera& out, std::string& err);
 
 }  // namespace rtb

@@ -48,6 +48,10 @@ hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* 
                             DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err, DBvh4Node* existing = nullptr,
                             uint32_t n_existing = 0);
 
+/* The 64-byte nodes the rays fetch (DBvh4Q, rt_types.h) from the four-wide table, node for node; d_out holds n4 of them.
+ * Enqueued on `stream`. */
+hipError_t quantise_bvh4(const DBvh4Node* d_bvh4, uint32_t n4, DBvh4Q* d_out, hipStream_t stream);
+
 /* Refit: the vertices moved, the triangles and the trees stay.
  * vertex_box: exact box of `count` raw positions into d_box (8 words, box_init / box_decode).
  * remake_mesh_tris: the `count` records at d_tris (any order -- after a build, leaf order) again from the vertex ids they

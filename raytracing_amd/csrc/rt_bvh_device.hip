@@ -298,6 +298,47 @@ __global__ void __launch_bounds__(256) k_collapse(const DBvhNode* nodes, uint32_
     out[rank[i]] = o;
 }
 
+/* DBvh4Node -> DBvh4Q, one thread per node.  The node's box is the union of its children's; scale[a] is chosen so that the
+ * largest code, 255, reaches the upper face; every code is then checked against the very expression the traversal evaluates
+ * (fmaf(q, scale, lo)) and moved outwards until the decoded bound encloses the child's. */
+__global__ void __launch_bounds__(256) k_quantise(const DBvh4Node* in, uint32_t n4, DBvh4Q* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const DBvh4Node n = in[i];
+    const float* lo[4] = {n.half[0].lo0, n.half[0].lo1, n.half[1].lo0, n.half[1].lo1};
+    const float* hi[4] = {n.half[0].hi0, n.half[0].hi1, n.half[1].hi0, n.half[1].hi1};
+    const int32_t c[4] = {n.half[0].c0, n.half[0].c1, n.half[1].c0, n.half[1].c1};
+    const int32_t cnt[4] = {n.half[0].n0, n.half[0].n1, n.half[1].n0, n.half[1].n1};
+    DBvh4Q o;
+    bool used[4];
+    for (int k = 0; k < 4; ++k) {
+        used[k] = !child_empty(c[k], cnt[k]);
+        o.child[k] = !used[k] ? RT_BVH4Q_EMPTY : (cnt[k] > 0 ? ~(c[k] * 8 + cnt[k]) : c[k]);
+    }
+    for (int a = 0; a < 3; ++a) {
+        float nlo = INFINITY, nhi = -INFINITY;
+        for (int k = 0; k < 4; ++k) if (used[k]) { nlo = fminf(nlo, lo[k][a]); nhi = fmaxf(nhi, hi[k][a]); }
+        if (!(nlo <= nhi)) { nlo = 0.f; nhi = 0.f; }
+        float sc = (nhi - nlo) / 255.0f;
+        if (!(sc > 0.f)) sc = 1e-30f;
+        while (fmaf(255.0f, sc, nlo) < nhi) sc = __int_as_float(__float_as_int(sc) + 1); /* a few steps at most */
+        o.lo[a] = nlo; o.scale[a] = sc;
+        uint32_t wlo = 0, whi = 0;
+        for (int k = 0; k < 4; ++k) {
+            int ql = 255, qh = 0; /* an unused slot gets the empty box */
+            if (used[k]) {
+                ql = (int)floorf((lo[k][a] - nlo) / sc); ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+                while (ql > 0 && fmaf((float)ql, sc, nlo) > lo[k][a]) --ql;
+                qh = (int)ceilf((hi[k][a] - nlo) / sc); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                while (qh < 255 && fmaf((float)qh, sc, nlo) < hi[k][a]) ++qh;
+            }
+            wlo |= (uint32_t)ql << (8 * k); whi |= (uint32_t)qh << (8 * k);
+        }
+        o.q[a] = wlo; o.q[3 + a] = whi;
+    }
+    out[i] = o;
+}
+
 /* ---- refit: new vertex positions, same triangles, same trees ------------------------------------------------- */
 /* exact box of the raw positions of one mesh's vertices (what Scene::computeGlobalAABB grows the root box by) */
 __global__ void __launch_bounds__(256) k_vertex_box(const float* positions, uint32_t count, uint32_t* box) {
@@ -566,6 +607,12 @@ hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* 
     if (e != hipSuccess) { if (!existing) (void)hipFree(out); err = std::string("four-wide BVH: ") + hipGetErrorString(e); return e; }
     *d_bvh4 = out; *n4 = total;
     return hipSuccess;
+}
+
+hipError_t quantise_bvh4(const DBvh4Node* d_bvh4, uint32_t n4, DBvh4Q* d_out, hipStream_t stream) {
+    if (n4 == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_quantise, dim3(blocks(n4)), dim3(256), 0, stream, d_bvh4, n4, d_out);
+    return hipGetLastError();
 }
 
 hipError_t vertex_box(const float* d_positions, uint32_t count, uint32_t* d_box, hipStream_t stream) {

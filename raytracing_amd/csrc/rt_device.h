@@ -299,7 +299,12 @@ RT_DEV bool slab(const float lo[3], const float hi[3], f3 o, f3 id, float limit,
  * carry a rounding error of a few 2^-24 * c2, d is unit to 2^-23: the 1e-6 * c2 slack keeps every rejection
  * certain; NaN / inf operands reject nothing), then the padded root box.  limit = FLT_MAX for a closest-hit
  * query, the distance to the light for a shadow ray. */
-RT_DEV f3 bvh_inv_dir(f3 d) { return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
+/* 1 / d per axis for the box tests, kept finite: a direction component of exactly zero would give an infinite factor, and the
+ * node test evaluates a bound as code * (scale * id) + (lo - o) * id, where inf - inf is NaN and the axis would stop
+ * constraining anything -- such a ray walks every node along that axis (one lane was seen to visit 5 500 nodes where its
+ * neighbours visit 180).  With +-1e18 instead, an origin outside the slab still yields a distance beyond every limit. */
+RT_DEV float bvh_inv(float x) { return fminf(fmaxf(__builtin_amdgcn_rcpf(x), -1e18f), 1e18f); }
+RT_DEV f3 bvh_inv_dir(f3 d) { return mk3(bvh_inv(d.x), bvh_inv(d.y), bvh_inv(d.z)); }
 template <bool ANY>
 RT_DEV bool bvh_reaches(const DMesh& m, f3 o, f3 d, float limit) {
     const f3 oc = ld3(m.bs_c) - o;
@@ -311,31 +316,40 @@ RT_DEV bool bvh_reaches(const DMesh& m, f3 o, f3 d, float limit) {
     float tn;
     return slab(m.lo, m.hi, o, bvh_inv_dir(d), limit, tn);
 }
-/* The traversal proper; the caller has checked bvh_reaches.  It walks the four-wide tree (DBvh4Node): one 128-byte fetch
- * decides among four subtrees, the hit ones are visited nearest first.  Stack: RT_STACK_LDS entries in LDS, and what a
+/* The traversal proper; the caller has checked bvh_reaches.  It walks the four-wide tree in its 64-byte form (DBvh4Q): one
+ * fetch of four dwordx4 decides among four subtrees, the hit ones are visited nearest first.  Stack: RT_STACK_LDS entries in LDS, and what a
  * path could need beyond them (three pushes per level, RT_STACK_LDS / 2 levels at most) in a small per-lane array. */
 #define RT_STACK_OVER (RT_STACK_LDS / 2)
 /* The four child boxes of a wide node against a ray: how many the ray reaches within `limit`, and their stack entries
  * (>= 0 inner node, < 0 leaf) ordered by entry distance, e0 the nearest. */
-RT_DEV int bvh4_order(const DBvh4Node& n, f3 o, f3 id, float limit, int& e0, int& e1, int& e2, int& e3) {
-    float t0, t1, t2, t3;
-    const DBvhNode& a = n.half[0];
-    const DBvhNode& b = n.half[1];
-    const bool h0 = slab(a.lo0, a.hi0, o, id, limit, t0) && !(a.n0 == 0 && a.c0 < 0);
-    const bool h1 = slab(a.lo1, a.hi1, o, id, limit, t1) && !(a.n1 == 0 && a.c1 < 0);
-    const bool h2 = slab(b.lo0, b.hi0, o, id, limit, t2) && !(b.n0 == 0 && b.c0 < 0);
-    const bool h3 = slab(b.lo1, b.hi1, o, id, limit, t3) && !(b.n1 == 0 && b.c1 < 0);
-    e0 = a.n0 > 0 ? ~(a.c0 * 8 + a.n0) : a.c0; e1 = a.n1 > 0 ? ~(a.c1 * 8 + a.n1) : a.c1;
-    e2 = b.n0 > 0 ? ~(b.c0 * 8 + b.n0) : b.c0; e3 = b.n1 > 0 ? ~(b.c1 * 8 + b.n1) : b.c1;
+RT_DEV int bvh4_order(const DBvh4Q& n, f3 o, f3 id, float limit, int& e0, int& e1, int& e2, int& e3) {
+    /* entry / exit distance along an axis of a bound stored as code q: ((lo + q scale) - o) id = q (scale id) + (lo - o) id */
+    const f3 A = mk3(n.scale[0] * id.x, n.scale[1] * id.y, n.scale[2] * id.z);
+    const f3 B = mk3((n.lo[0] - o.x) * id.x, (n.lo[1] - o.y) * id.y, (n.lo[2] - o.z) * id.z);
+    float tn[4];
+    bool h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto code = [&](uint32_t w) { return (float)((w >> (8 * k)) & 255u); }; /* byte k of w as a float: one v_cvt_f32_ubyte<k> */
+        const float x1 = __builtin_fmaf(code(n.q[0]), A.x, B.x), x2 = __builtin_fmaf(code(n.q[3]), A.x, B.x);
+        const float y1 = __builtin_fmaf(code(n.q[1]), A.y, B.y), y2 = __builtin_fmaf(code(n.q[4]), A.y, B.y);
+        const float z1 = __builtin_fmaf(code(n.q[2]), A.z, B.z), z2 = __builtin_fmaf(code(n.q[5]), A.z, B.z);
+        /* fminf / fmaxf drop a NaN operand (0 * inf when the ray runs inside a face plane): that axis then does not constrain
+         * the interval, which is the conservative reading (as in slab) */
+        tn[k] = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.f));
+        const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), limit));
+        h[k] = tn[k] <= tf && n.child[k] != RT_BVH4Q_EMPTY;
+    }
+    e0 = n.child[0]; e1 = n.child[1]; e2 = n.child[2]; e3 = n.child[3];
     /* entry distances, +inf for a child that is not visited; sorted ascending by a five-comparator network */
-    float k0 = h0 ? t0 : RT_INF, k1 = h1 ? t1 : RT_INF, k2 = h2 ? t2 : RT_INF, k3 = h3 ? t3 : RT_INF;
+    float k0 = h[0] ? tn[0] : RT_INF, k1 = h[1] ? tn[1] : RT_INF, k2 = h[2] ? tn[2] : RT_INF, k3 = h[3] ? tn[3] : RT_INF;
     auto order = [](float& ka, int& ea, float& kb, int& eb) {
         const bool sw = kb < ka;
         const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt;
         const int et = sw ? eb : ea; eb = sw ? ea : eb; ea = et;
     };
     order(k0, e0, k1, e1); order(k2, e2, k3, e3); order(k0, e0, k2, e2); order(k1, e1, k3, e3); order(k1, e1, k2, e2);
-    return (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    return (int)h[0] + (int)h[1] + (int)h[2] + (int)h[3];
 }
 template <bool ANY>
 RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float dist, Cnt& cnt, float& best_t, int& best_tri,
@@ -357,8 +371,8 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
     };
     int cur = m.bvh4_root;
     bool done = false;
-    auto visit = [&](const DBvh4Node& n) { /* the four child boxes of one node: where to go next, what to keep for later */
-        cnt.bvh_nodes += 2; /* counted in 64-byte units */
+    auto visit = [&](const DBvh4Q& n) { /* the four child boxes of one node: where to go next, what to keep for later */
+        cnt.bvh_nodes += 1; /* counted in 64-byte units */
         int e0, e1, e2, e3;
         const int hits = bvh4_order(n, o, id, best_t, e0, e1, e2, e3);
         if (hits > 3) push(e3);
@@ -369,9 +383,9 @@ RT_DEV bool bvh_walk(const DeviceScene& sc, const DMesh& m, f3 o, f3 d, float di
         else done = true;
     };
     /* the root is the same node for every lane: its address is wave-uniform, so this fetch is a scalar load */
-    visit(ldc(&sc.bvh4[m.bvh4_root]));
+    visit(ldc(&sc.bvh4q[m.bvh4_root]));
     for (;;) {
-        while (!done && cur >= 0) visit(ldc(&sc.bvh4[cur])); /* inner nodes */
+        while (!done && cur >= 0) visit(ldc(&sc.bvh4q[cur])); /* inner nodes */
         if (done) break;
         { /* leaf */
             int code = ~cur;
@@ -1078,13 +1092,13 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
 #ifdef RT_WALK_STATS
                 const unsigned long long w0 = __builtin_readcyclecounter();
 #endif
-                const DBvh4Node n = ldc(&sc.bvh4[cur]);
+                const DBvh4Q n = ldc(&sc.bvh4q[cur]);
 #ifdef RT_WALK_STATS
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 report.wait_cycles += __builtin_readcyclecounter() - w0; /* of the lane that reports: issue to arrival of a node */
                 ++report.waits;
 #endif
-                cnt.bvh_nodes += 2;
+                cnt.bvh_nodes += 1;
                 int e0, e1, e2, e3;
                 const int hits = bvh4_order(n, ro, id, rdist, e0, e1, e2, e3);
                 if (hits > 3) push(e3);

@@ -86,6 +86,20 @@ struct DBvh4Node {
     DBvhNode half[2];
 };
 
+/* The same node in 64 bytes (four dwordx4 loads, two nodes per cache line): what the rays fetch.  The four child boxes are
+ * stored relative to the node's own box -- the union of its children -- with 8 bits per bound: bound = lo[a] + q * scale[a],
+ * lower bounds rounded down, upper bounds rounded up, so a quantised box encloses the box of the 128-byte node (whose pad it
+ * inherits) and can only make a walk visit more, never less.  q[b] holds bound b (lo x, lo y, lo z, hi x, hi y, hi z) of the
+ * four children, one byte each (child k in byte k: v_cvt_f32_ubyte<k>).  child[k]: >= 0 inner node, < 0 a leaf, ~child =
+ * first triangle * 8 + count (the traversal's stack entries), RT_BVH4Q_EMPTY for an unused slot. */
+#define RT_BVH4Q_EMPTY ((int32_t)0x80000000)
+struct DBvh4Q {
+    float lo[3];
+    float scale[3];
+    uint32_t q[6];
+    int32_t child[4];
+};
+
 /* Shadow rays of a quad light against a square, decided without the square's arithmetic.  A sample of the light is
  * S(u, v) = (1 - u - v) p0 + u p1 + v p2 (R/src/Scene.h:252-276), its shadow ray runs from so = P + 0.001 N along S - P for
  * the length |S - P|, i.e. to S + 0.001 N.  The numerator of Square::intersect, dot(v0 - X, n) (R/src/Square.h:86-88), is
@@ -124,7 +138,8 @@ struct DeviceScene {
     const DTri* tris;           /* per mesh: original order (brute force) or BVH leaf order */
     const uint32_t* tri_orig;   /* mesh-local original index of tris[i]: tIndex and the tie-break */
     const DBvhNode* bvh;        /* binary trees as built (kept for verification) */
-    const DBvh4Node* bvh4;      /* their four-wide form, what bvh_walk traverses */
+    const DBvh4Node* bvh4;      /* their four-wide form with full-precision boxes (made from bvh, kept for verification and refit) */
+    const DBvh4Q* bvh4q;        /* the same nodes, same indices, with quantised boxes: what bvh_walk traverses */
     const float* normals;  /* xyz per vertex */
     const DMaterial* materials;
     const DLight* lights;
