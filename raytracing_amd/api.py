@@ -161,7 +161,7 @@ def init(device=0):
 
 
 def set_option(name, value):
-    """rt_set_option: scheduling switches ("tile_order", "wide", "wide_nodes"); results never depend on them."""
+    """rt_set_option: scheduling switches ("tile_order", "wide", "wide_nodes", "treelet_order"); results never depend on them."""
     check(lib().rt_set_option(name.encode(), int(value)))
 
 

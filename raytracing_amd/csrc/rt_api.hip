@@ -54,11 +54,11 @@ namespace {
             default: hipLaunchKernelGGL((kernel<3, T>), grid, dim3(T), 0, stream, __VA_ARGS__); break; \
         }                                                                                              \
     } while (0)
-/* Every variant but the one for kd-trees with internal nodes exists with and without the worker code, and a launch
+/* Every variant exists with and without the worker code, and a launch
  * without workers takes the one without (measured: 100 k-triangle frame 36.5 -> 35.1 ms, 1 M-triangle frame 1 % faster,
  * the Cornell frame unchanged at 20.6 ms -- but 384 instead of 544 bytes of scratch per lane and a third of the spills). */
 #define RT_RENDER_CASE(m, p, grid, stream, ...) \
-    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, (m) == 1>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break; \
+    case (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, false>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break; \
     case 8 + (m) * 2 + (p): hipLaunchKernelGGL((k_render<m, (p) != 0, true>), grid, dim3(64 * RT_RENDER_WAVES), 0, stream, __VA_ARGS__); break;
 #define RT_DISPATCH_RENDER(mode, pack, workers, grid, stream, ...)                                     \
     do {                                                                                               \
@@ -76,6 +76,7 @@ struct SceneRes {
     int mode = 0;
     bool has_bounce = false; /* some sphere is a mirror or glass: only then do path trees differ in depth */
     size_t n_tris = 0, n_bvh = 0, n_bvh4 = 0, n_normals = 0; /* lengths of the device tables (their host copies are dropped) */
+    const uint32_t* bvh4_place = nullptr; /* device: where each wide node of the collapse went (treelet order), null = collapse order */
     int bvh_depth = 0;
     rt_build_times times{};
     std::vector<void*> allocs;
@@ -109,6 +110,9 @@ struct Lib {
     uint32_t order_deep_cap[kOrderSlots] = {};
     size_t order_colors_bytes[kOrderSlots] = {};
     int wide = 1;               /* RTAMD_WIDE: 0 = every path tree depth first, 1 = breadth-first workers where they pay, 2 = wherever something bounces */
+    bool treelet_order = false; /* RTAMD_TREELET_ORDER=1 / option "treelet_order": scenes created from now on keep their wide nodes in treelet
+                                 * order.  Off by default: frame times and L2 hit rates of the mesh workloads were the same with it (the misses
+                                 * are scratch writes and first touches, not neighbours of nodes just fetched), and it costs a second collapse. */
     uint32_t wide_nodes = 12; /* RTAMD_WIDE_NODES: path nodes of the centre ray from which a pixel counts as deep */
     unsigned order_next = 0;
     /* A ring slot is handed out again after kCamSlots / kOrderSlots further calls.  The launches that read it may
@@ -307,6 +311,18 @@ int bvh4_on_device(SceneRes* r) {
     r->dev.bvh4q = qnodes;
     HIP_TRY(rtd::quantise_bvh4(nodes, n4, qnodes, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    if (g.treelet_order && n4 > 1) { /* the same trees once more, every node written to its place in treelet order */
+        uint32_t* place = nullptr;
+        e = rtd::treelet_places(qnodes, n4, roots4.data(), (uint32_t)roots4.size(), &place, err);
+        if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_create: " + err);
+        r->allocs.push_back(place);
+        r->bvh4_place = place;
+        DBvh4Node* same = nullptr;
+        e = rtd::collapse_to_bvh4(r->dev.bvh, (uint32_t)r->n_bvh, roots.data(), (uint32_t)roots.size(), g.stream, &same, &n4, roots4.data(), err, nodes, n4, place);
+        if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_create: " + err);
+        HIP_TRY(rtd::quantise_bvh4(nodes, n4, qnodes, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+    }
     for (size_t k = 0; k < owner.size(); ++k) r->host.meshes[owner[k]].bvh4_root = roots4[k];
     return RT_OK;
 }
@@ -368,6 +384,8 @@ int rt_init(int device) {
     const char* wn = std::getenv("RTAMD_WIDE_NODES");
     g.wide_nodes = 12;
     if (wn && std::atoi(wn) >= 1 && std::atoi(wn) <= RT_PROBE_CAP) g.wide_nodes = (uint32_t)std::atoi(wn);
+    const char* to = std::getenv("RTAMD_TREELET_ORDER");
+    g.treelet_order = to && to[0] == '1';
     g.device = device;
     g.ready = true;
     return RT_OK;
@@ -377,6 +395,7 @@ int rt_set_option(const char* name, int64_t value) {
     if (!name) return fail(RT_E_INVALID, "rt_set_option: null name");
     const std::string k(name);
     if (k == "tile_order") g.order_tiles = value != 0;
+    else if (k == "treelet_order") g.treelet_order = value != 0;
     else if (k == "wide") {
         if (value < 0 || value > 2) return fail(RT_E_INVALID, "rt_set_option: wide must be 0, 1 or 2");
         g.wide = (int)value;
@@ -478,8 +497,8 @@ int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene_t* ou
         (rc = upload(r, r->host.bvh, &d.bvh)) ||
         (rc = upload(r, r->host.normals, &d.normals)) || (rc = upload(r, r->host.materials, &d.materials)) ||
         (rc = upload(r, r->host.lights, &d.lights)) || (rc = upload(r, r->host.kd, &d.kd)) ||
-        (rc = upload(r, r->host.refs, &d.refs)) || (rc = upload(r, r->host.ref_spheres, &d.ref_spheres)) ||
-        (rc = upload(r, r->host.ref_squares, &d.ref_squares)) || (rc = upload(r, r->host.light_sq, &d.light_sq))) {
+        (rc = upload(r, r->host.refs, &d.refs)) || (rc = upload(r, r->host.leaf_recs, &d.leaf_recs)) ||
+        (rc = upload(r, r->host.light_sq, &d.light_sq))) {
         release(r);
         return rc;
     }
@@ -643,7 +662,7 @@ int rt_scene_refit(rt_scene_t scene, const float* positions, const float* normal
         DBvh4Node* same = nullptr;
         uint32_t n4 = 0;
         e = rtd::collapse_to_bvh4(r->dev.bvh, (uint32_t)r->n_bvh, roots.data(), (uint32_t)roots.size(), g.stream, &same, &n4, roots4.data(), err,
-                                  const_cast<DBvh4Node*>(r->dev.bvh4), (uint32_t)r->n_bvh4);
+                                  const_cast<DBvh4Node*>(r->dev.bvh4), (uint32_t)r->n_bvh4, r->bvh4_place);
         if (e != hipSuccess) return fail(RT_E_HIP, "rt_scene_refit: " + err);
         HIP_TRY(rtd::quantise_bvh4(r->dev.bvh4, (uint32_t)r->n_bvh4, const_cast<DBvh4Q*>(r->dev.bvh4q), g.stream));
     }

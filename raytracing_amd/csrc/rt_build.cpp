@@ -629,11 +629,14 @@ bool build_scene(const rt_scene_desc& d, Built& out, std::string& err, bool defe
     for (uint32_t i = 0; i < d.n_meshes; ++i) out.refs.push_back(DRef{RT_MESH, (int32_t)i});
     build_node(d, out, root, 0, (int32_t)out.refs.size(), 0);
     if (!out.kd.empty() && !out.kd[0].leaf) { /* leaves of a real tree read their objects' records in reference order */
-        out.ref_spheres.assign(out.refs.size(), DSphere{});
-        out.ref_squares.assign(out.refs.size(), DSquare{});
+        DLeafRec none;
+        std::memset(&none, 0, sizeof(none));
+        out.leaf_recs.assign(out.refs.size(), none);
         for (size_t r = 0; r < out.refs.size(); ++r) {
-            if (out.refs[r].type == RT_SPHERE) out.ref_spheres[r] = out.spheres[(size_t)out.refs[r].object];
-            if (out.refs[r].type == RT_SQUARE) out.ref_squares[r] = out.squares[(size_t)out.refs[r].object];
+            DLeafRec& rec = out.leaf_recs[r];
+            rec.type = out.refs[r].type; rec.object = out.refs[r].object;
+            if (rec.type == RT_SPHERE) rec.u.s = out.spheres[(size_t)rec.object];
+            if (rec.type == RT_SQUARE) rec.u.q = out.squares[(size_t)rec.object];
         }
     }
     out.kd_epsilon = d.kd_epsilon;

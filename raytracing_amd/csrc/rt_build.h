@@ -22,8 +22,7 @@ struct Built {
     std::vector<DLight> lights;
     std::vector<DKdNode> kd;   /* kd[0] = root, pre-order */
     std::vector<DRef> refs;    /* leaf slices, list order of the reference */
-    std::vector<DSphere> ref_spheres; /* with internal kd nodes: the records in reference order (see DeviceScene) */
-    std::vector<DSquare> ref_squares;
+    std::vector<DLeafRec> leaf_recs; /* with internal kd nodes: the records in reference order (see DeviceScene) */
     std::vector<DLightSq> light_sq; /* DeviceScene::light_sq */
     float cert_radius = 0.f;      /* DeviceScene::cert_radius */
     float box_lo[3], box_hi[3];

@@ -43,10 +43,16 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
  * kept and takes over the children of its inner children.  d_bvh2[0, n2): the binary nodes of all meshes (child
  * indices into the same table); roots[0, n_roots): the root nodes, roots4 gets their positions in the new table.
  * The new table comes back in a fresh device array (hipFree by the caller) -- or, when `existing` is given (a table of
- * n_existing nodes made from the same trees: a refit), in that one.  Blocks until done. */
+ * n_existing nodes made from the same trees: a refit), in that one.  d_place (device, one entry per wide node in the
+ * order without it, or null) moves every node to the place it names; roots4 then holds the moved positions.
+ * Blocks until done. */
 hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, uint32_t n_roots, hipStream_t stream,
                             DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err, DBvh4Node* existing = nullptr,
-                            uint32_t n_existing = 0);
+                            uint32_t n_existing = 0, const uint32_t* d_place = nullptr);
+
+/* Places for collapse_to_bvh4 that put the table into treelet order (depth first; the inner children of a node side by
+ * side), computed on the host from the 64-byte table of a first collapse.  *d_place: fresh device array (hipFree by the caller). */
+hipError_t treelet_places(const DBvh4Q* d_nodes, uint32_t n4, const int32_t* roots4, uint32_t n_roots, uint32_t** d_place, std::string& err);
 
 /* The 64-byte nodes the rays fetch (DBvh4Q, rt_types.h) from the four-wide table, node for node; d_out holds n4 of them.
  * Enqueued on `stream`. */

@@ -271,7 +271,8 @@ __device__ inline void put_child(DBvh4Node& o, int slot, const float* lo, const 
     if (slot & 1) { h.c1 = c; h.n1 = n; } else { h.c0 = c; h.n0 = n; }
 }
 
-__global__ void __launch_bounds__(256) k_collapse(const DBvhNode* nodes, uint32_t n2, const uint32_t* keep, const uint32_t* rank, DBvh4Node* out) {
+/* place: where each wide node (numbered by rank) goes in the table, or null for rank order */
+__global__ void __launch_bounds__(256) k_collapse(const DBvhNode* nodes, uint32_t n2, const uint32_t* keep, const uint32_t* rank, const uint32_t* place, DBvh4Node* out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n2 || !keep[i]) return;
     const DBvhNode n = nodes[i];
@@ -291,11 +292,12 @@ __global__ void __launch_bounds__(256) k_collapse(const DBvhNode* nodes, uint32_
         const int32_t mc[2] = {m.c0, m.c1}, mn[2] = {m.n0, m.n1};
         for (int j = 0; j < 2; ++j) {
             if (child_empty(mc[j], mn[j])) continue;
-            const int32_t code = child_inner(mc[j], mn[j]) ? (int32_t)rank[mc[j]] : mc[j];
+            int32_t code = mc[j];
+            if (child_inner(mc[j], mn[j])) code = (int32_t)(place ? place[rank[mc[j]]] : rank[mc[j]]);
             put_child(o, slot++, mlo[j], mhi[j], code, mn[j]);
         }
     }
-    out[rank[i]] = o;
+    out[place ? place[rank[i]] : rank[i]] = o;
 }
 
 /* DBvh4Node -> DBvh4Q, one thread per node.  The node's box is the union of its children's; scale[a] is chosen so that the
@@ -572,7 +574,8 @@ hipError_t build_mesh_bvh(DTri* d_tris, uint32_t* d_tri_orig, uint32_t first, ui
 }
 
 hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* roots, uint32_t n_roots, hipStream_t stream,
-                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err, DBvh4Node* existing, uint32_t n_existing) {
+                            DBvh4Node** d_bvh4, uint32_t* n4, int32_t* roots4, std::string& err, DBvh4Node* existing, uint32_t n_existing,
+                            const uint32_t* d_place) {
     *d_bvh4 = nullptr; *n4 = 0;
     if (n2 == 0) return hipSuccess;
     Temps tmp;
@@ -598,14 +601,53 @@ hipError_t collapse_to_bvh4(const DBvhNode* d_bvh2, uint32_t n2, const int32_t* 
         BVH_TRY(hipMemcpyAsync(&roots4[k], rank + roots[k], 4, hipMemcpyDeviceToHost, stream));
     }
     BVH_TRY(hipStreamSynchronize(stream));
+    if (d_place)
+        for (uint32_t k = 0; k < n_roots; ++k) BVH_TRY(hipMemcpy(&roots4[k], d_place + roots4[k], 4, hipMemcpyDeviceToHost));
     DBvh4Node* out = existing;
     if (existing && n_existing != total) { err = "four-wide BVH: the table to refresh has another size"; return hipErrorInvalidValue; }
     if (!existing) BVH_TRY(hipMalloc((void**)&out, (size_t)(total ? total : 1) * sizeof(DBvh4Node)));
-    hipLaunchKernelGGL(k_collapse, dim3(blocks(n2)), dim3(256), 0, stream, d_bvh2, n2, (const uint32_t*)keep, (const uint32_t*)rank, out);
+    hipLaunchKernelGGL(k_collapse, dim3(blocks(n2)), dim3(256), 0, stream, d_bvh2, n2, (const uint32_t*)keep, (const uint32_t*)rank, d_place, out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) { if (!existing) (void)hipFree(out); err = std::string("four-wide BVH: ") + hipGetErrorString(e); return e; }
     *d_bvh4 = out; *n4 = total;
+    return hipSuccess;
+}
+
+/* Table order by treelets: depth first over the trees, and at every node the inner children of that node get consecutive
+ * places before any of them is descended into -- the two to four nodes a ray may visit next lie within 256 bytes, and the
+ * subtree below a node is one contiguous run of the table. */
+hipError_t treelet_places(const DBvh4Q* d_nodes, uint32_t n4, const int32_t* roots4, uint32_t n_roots, uint32_t** d_place, std::string& err) {
+    *d_place = nullptr;
+    if (n4 == 0) return hipSuccess;
+    std::vector<DBvh4Q> nodes(n4);
+    BVH_TRY(hipMemcpy(nodes.data(), d_nodes, (size_t)n4 * sizeof(DBvh4Q), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> place(n4, 0xffffffffu), todo;
+    uint32_t next = 0;
+    for (uint32_t k = 0; k < n_roots; ++k) {
+        if (roots4[k] < 0 || (uint32_t)roots4[k] >= n4 || place[roots4[k]] != 0xffffffffu) { err = "four-wide BVH: bad root"; return hipErrorInvalidValue; }
+        place[roots4[k]] = next++;
+        todo.push_back((uint32_t)roots4[k]);
+        while (!todo.empty()) {
+            const uint32_t at = todo.back();
+            todo.pop_back();
+            const DBvh4Q& n = nodes[at];
+            for (int s = 0; s < 4; ++s) {
+                const int32_t c = n.child[s];
+                if (c < 0) continue; /* leaf or unused */
+                if ((uint32_t)c >= n4 || place[c] != 0xffffffffu) { err = "four-wide BVH: a node has two parents"; return hipErrorInvalidValue; }
+                place[c] = next++;
+            }
+            for (int s = 3; s >= 0; --s) if (n.child[s] >= 0) todo.push_back((uint32_t)n.child[s]);
+        }
+    }
+    for (uint32_t i = 0; i < n4; ++i) if (place[i] == 0xffffffffu) place[i] = next++; /* nodes no root reaches keep a slot */
+    if (next != n4) { err = "four-wide BVH: order does not cover the table"; return hipErrorInvalidValue; }
+    uint32_t* d = nullptr;
+    BVH_TRY(hipMalloc((void**)&d, (size_t)n4 * 4));
+    hipError_t e = hipMemcpy(d, place.data(), (size_t)n4 * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); err = std::string("four-wide BVH: ") + hipGetErrorString(e); return e; }
+    *d_place = d;
     return hipSuccess;
 }
 

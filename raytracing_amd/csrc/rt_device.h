@@ -476,28 +476,30 @@ RT_DEV bool square_surely_behind(const DSquare& q, f3 o, f3 d) {
     return dot3(ld3(q.v0) - o, n) * __builtin_amdgcn_rcpf(dot3(d, n)) < -1e-30f;
 }
 
-/* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------ */
+/* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------
+ * One object of a leaf against one ray: the object's own intersect routine behind the certain-miss tests. */
+template <int M>
+RT_DEV bool leaf_object(const DeviceScene& sc, int type, int object, const DSphere& s, const DSquare& q, f3 o, f3 d, Cnt& cnt,
+                        float& t, int& tri, float& u, float& v) {
+    if (type == RT_SPHERE) return !sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t);
+    if (type == RT_SQUARE) return !square_surely_behind(q, o, d) && square_t(q, o, d, t);
+    return mesh_closest<M>(sc, ldc(&sc.meshes[object]), o, d, cnt, t, tri, u, v);
+}
+RT_DEV void leaf_keep(HitRec& best, int type, int object, float t, int tri, float u, float v) {
+    if (best.type < 0 || t < best.t) { best.t = t; best.type = type; best.obj = object; best.tri = tri; best.u = u; best.v = v; }
+}
+/* Every lane walks the references of its own leaf (the lanes of the wave may be in different leaves: vector loads). */
 template <int M>
 RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, Cnt& cnt, HitRec& best) {
     bool any = false;
     for (int r = first; r < first + count; ++r) {
-        DRef ref = ldc(&sc.refs[r]);
+        const DLeafRec* rec = &sc.leaf_recs[r];
+        const int type = ldc(&rec->type), object = ldc(&rec->object);
         float t = 0.f, u = 0.f, v = 0.f;
         int tri = -1;
-        bool ok;
-        /* with internal nodes (M & RT_M_KD) the record sits at the reference's own position: its address does not
-         * wait for the reference to arrive */
-        if (ref.type == RT_SPHERE) {
-            const DSphere s = (M & RT_M_KD) ? ldc(&sc.ref_spheres[r]) : ldc(&sc.spheres[ref.object]);
-            ok = !sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t);
-        } else if (ref.type == RT_SQUARE) {
-            const DSquare q = (M & RT_M_KD) ? ldc(&sc.ref_squares[r]) : ldc(&sc.squares[ref.object]);
-            ok = !square_surely_behind(q, o, d) && square_t(q, o, d, t);
-        } else ok = mesh_closest<M>(sc, ldc(&sc.meshes[ref.object]), o, d, cnt, t, tri, u, v);
-        if (ok) {
-            any = true;
-            if (best.type < 0 || t < best.t) { best.t = t; best.type = ref.type; best.obj = ref.object; best.tri = tri; best.u = u; best.v = v; }
-        }
+        DSphere s; DSquare q;
+        if (type == RT_SPHERE) s = ldc(&rec->u.s); else if (type == RT_SQUARE) q = ldc(&rec->u.q);
+        if (leaf_object<M>(sc, type, object, s, q, o, d, cnt, t, tri, u, v)) { any = true; leaf_keep(best, type, object, t, tri, u, v); }
     }
     return any;
 }
@@ -550,15 +552,25 @@ RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, fl
         DRef ref = ldc(&sc.refs[r]);
         float t;
         if (ref.type == RT_SPHERE) {
-            const DSphere s = (M & RT_M_KD) ? ldc(&sc.ref_spheres[r]) : ldc(&sc.spheres[ref.object]);
-            if (!sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t) && t < dist) return true;
+            if (sphere_t(ldc(&sc.spheres[ref.object]), o, d, t) && t < dist) return true;
         } else if (ref.type == RT_SQUARE) {
-            const DSquare q = (M & RT_M_KD) ? ldc(&sc.ref_squares[r]) : ldc(&sc.squares[ref.object]);
-            if (!square_surely_behind(q, o, d) && square_t(q, o, d, t) && t < dist) return true;
+            if (square_t(ldc(&sc.squares[ref.object]), o, d, t) && t < dist) return true;
         }
         else { if (mesh_any<M>(sc, ldc(&sc.meshes[ref.object]), o, d, dist, cnt)) return true; }
     }
     return false;
+}
+/* The leaf loop for lanes that are all in the same leaf (first, count wave-uniform): the records arrive by scalar loads, each
+ * requested while the one before it is tested, and the branch on the object's kind is the same for all lanes. */
+template <int M>
+RT_DEV bool leaf_closest_uniform(const DeviceScene& sc, int first, int count, f3 o, f3 d, Cnt& cnt, HitRec& best) {
+    bool any = false;
+    for_each_record(sc.leaf_recs + first, (uint32_t)count, [&](const DLeafRec& rec, uint32_t) {
+        float t = 0.f, u = 0.f, v = 0.f;
+        int tri = -1;
+        if (leaf_object<M>(sc, rec.type, rec.object, rec.u.s, rec.u.q, o, d, cnt, t, tri, u, v)) { any = true; leaf_keep(best, rec.type, rec.object, t, tri, u, v); }
+    });
+    return any;
 }
 
 /* ---- KDTree::intersectNode for internal nodes, R/src/KDTree.cpp:600-676 -------------------
@@ -566,6 +578,11 @@ RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, fl
  * boolean each call returns (something in that subtree was hit) is kept, because the reference
  * uses it to decide whether the far child is visited. */
 #define RT_KD_MAX_DEPTH 16
+/* The lanes of a wave run this together.  Every lane keeps its own traversal state; what is shared is the leaf loop: per trip
+ * the leaf of the first waiting lane is taken, and when at least half of the waiting lanes are in that very leaf (rays of one
+ * pixel, shadow rays of one point) they test its objects together from scalar-loaded records while the others wait for a
+ * later trip; otherwise every waiting lane walks its own leaf at once.  Which lanes share a trip changes no lane's sequence
+ * of tests. */
 template <int M>
 RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_out, Cnt& cnt, HitRec& best) {
     /* frame = far child id * 4 + state, plane distance, exit distance of the level.
@@ -573,11 +590,12 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
     int f_node[RT_KD_MAX_DEPTH];
     float f_split[RT_KD_MAX_DEPTH], f_out[RT_KD_MAX_DEPTH];
     int sp = 0, node = 0;
-    bool ret = false;
+    bool ret = false, done = false;
     for (;;) {
-        for (;;) { /* descend until a leaf */
+        int first = 0, count = 0;
+        while (!done) { /* descend until a leaf */
             DKdNode nd = ldc(&sc.kd[node]);
-            if (nd.leaf) { ret = leaf_closest<M>(sc, nd.first_ref, nd.n_refs, o, d, cnt, best); break; }
+            if (nd.leaf) { first = nd.first_ref; count = nd.n_refs; break; }
             float da = comp(d, nd.axis), oa = comp(o, nd.axis);
             float t_split = (__builtin_fabsf(da) < sc.kd_epsilon) ? RT_INF : (nd.cut - oa) / da;
             int near_id = (da >= 0.f) ? nd.left : nd.right;
@@ -585,11 +603,26 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
             if (t_split <= t_in) node = far_id;
             else if (t_split >= t_out) node = near_id;
             else {
-                if (sp >= RT_KD_MAX_DEPTH) return ret; /* unreachable: the host rejects deeper trees */
+                if (sp >= RT_KD_MAX_DEPTH) { done = true; break; } /* unreachable: the host rejects deeper trees */
                 f_node[sp] = far_id * 4; f_split[sp] = t_split; f_out[sp] = t_out; ++sp;
                 node = near_id; t_out = t_split;
             }
         }
+        const uint64_t waiting = __ballot(!done);
+        if (waiting == 0ull) return ret;
+        const int lead = (int)__builtin_ctzll(waiting);
+        const int lead_node = __builtin_amdgcn_readlane(node, lead);
+        const int lead_first = __builtin_amdgcn_readlane(first, lead), lead_count = __builtin_amdgcn_readlane(count, lead);
+        const bool with_lead = !done && node == lead_node;
+        bool tested;
+        if (2 * __popcll(__ballot(with_lead)) >= __popcll(waiting)) {
+            tested = with_lead;
+            if (with_lead) ret = leaf_closest_uniform<M>(sc, lead_first, lead_count, o, d, cnt, best);
+        } else {
+            tested = !done;
+            if (!done) ret = leaf_closest<M>(sc, first, count, o, d, cnt, best);
+        }
+        if (!tested) continue;
         bool resumed = false;
         while (sp > 0) { /* hand `ret` back to the waiting levels */
             int k = sp - 1;
@@ -608,7 +641,7 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
                 --sp;
             }
         }
-        if (!resumed) return ret;
+        if (!resumed) done = true;
     }
 }
 

@@ -757,18 +757,28 @@ __global__ __launch_bounds__(256) void k_prim_intersect(DeviceScene sc, int type
     out[i] = pack_hit(h, type, (int)object, -1, 0.f, 0.f);
 }
 
+/* Waves per SIMD, shadow-ray batch and LDS path-frame levels of k_trace, per scene variant (lane = ray).  Variant 0 is the
+ * one with a choice to make; the table it was taken from is printed by tools/ktrace_table.sh. */
 #ifndef RT_KTRACE_WAVES
 #define RT_KTRACE_WAVES 4
 #endif
+#ifndef RT_KTRACE_WAVES0
+#define RT_KTRACE_WAVES0 5
+#endif
+#ifndef RT_KTRACE_SB0
+#define RT_KTRACE_SB0 2
+#endif
+#ifndef RT_KTRACE_FRAMES0
+#define RT_KTRACE_FRAMES0 4
+#endif
 template <int M>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_KTRACE_WAVES, RT_KTRACE_WAVES))) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 0 ? RT_KTRACE_WAVES0 : RT_KTRACE_WAVES, M == 0 ? RT_KTRACE_WAVES0 : RT_KTRACE_WAVES))) void k_trace(DeviceScene sc, const float* __restrict__ org, const float* __restrict__ dir, size_t n,
                                                const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample, uint32_t seed,
                                                uint32_t k0, float* __restrict__ rgb, uint64_t* __restrict__ counters) {
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
-    /* 4 waves per SIMD and batches of four in every variant (lane = ray: six waves with batches of two, which pay in k_render's
-     * variant 0, make the Cornell batch 4 % slower here), the first levels of the path-frame stack in LDS where no BVH stack
-     * needs it */
-    constexpr int L = (M & RT_M_BVH) ? 0 : RT_FRAME_LDS;
+    /* the first levels of the path-frame stack in LDS where no BVH stack needs it */
+    constexpr int L = (M & RT_M_BVH) ? 0 : (M == 0 ? RT_KTRACE_FRAMES0 : RT_FRAME_LDS);
+    constexpr int SB = M == 0 ? RT_KTRACE_SB0 : RT_SB;
     __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 256 : 1];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE, s_frames + (L ? threadIdx.x : 0), 256);
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_KTRACE_W
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
         Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
-        f3 c = trace_path<M, false, L>(sc, o, d, rng, cnt);
+        f3 c = trace_path<M, false, L, SB>(sc, o, d, rng, cnt);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
         smp = 1;
     }

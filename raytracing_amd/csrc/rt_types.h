@@ -131,6 +131,13 @@ struct DKdNode {  /* 32 B */
 
 struct DRef { int32_t type; int32_t object; };
 
+/* kd-tree with internal nodes: everything a leaf's loop needs of reference r in one 96-byte record stored at r -- one fetch per
+ * object instead of reference -> record, and one scalar fetch for the whole wave where its lanes are in the same leaf. */
+struct DLeafRec {
+    int32_t type; int32_t object; int32_t pad[2];
+    union { DSphere s; DSquare q; } u; /* the record of a sphere / a square; zeros for a mesh (found through `object`) */
+};
+
 struct DeviceScene {
     const DSphere* spheres;
     const DSquare* squares;
@@ -145,8 +152,7 @@ struct DeviceScene {
     const DLight* lights;
     const DKdNode* kd;
     const DRef* refs;
-    const DSphere* ref_spheres; /* kd-tree with internal nodes only: the record of reference r, stored at r (valid where */
-    const DSquare* ref_squares; /* refs[r] names a sphere / a square): one fetch per object instead of two in a row   */
+    const DLeafRec* leaf_recs;  /* kd-tree with internal nodes only: the record of reference r, stored at r */
     /* per (light l, square q), at [l n_squares + q]: what decides, from the barycentric coordinates of a light sample alone,
      * whether its shadow ray can meet the square (DLightSq; null: every ray tests every square) */
     const DLightSq* light_sq;

@@ -122,3 +122,34 @@ def test_refit_of_two_meshes(flags):
         assert_hits_equal(want, g.mesh_intersect(m, org, dr), f"refitted mesh {m}")
     assert_hits_equal(o1.intersect(org, dr), g.intersect(org, dr), "refitted, two meshes")
     g.close()
+
+
+def test_treelet_order_changes_the_table_not_the_answers():
+    """The same two-mesh scene with its wide nodes in collapse order and in treelet order: both verify, hit records
+    and frames are the same bits, and a refit keeps the order it was built with."""
+    m1 = scenegen.grid_mesh(40, seed=3)
+    m2 = scenegen.grid_mesh(14, seed=4, size=0.5, center=(0.8, 0.2, -0.5))
+    d0, keep0 = scenegen.random_objects(orc, 1, 3, 5, with_mesh=m1, second_mesh=m2)
+    plain = api.DeviceScene(d0, keep=keep0, flags=api.BUILD_BVH_DEVICE)
+    api.set_option("treelet_order", 1)
+    try:
+        g = api.DeviceScene(d0, keep=keep0, flags=api.BUILD_BVH_DEVICE)
+    finally:
+        api.set_option("treelet_order", 0)
+    assert g.verify()[0].bvh_nodes == plain.verify()[0].bvh_nodes
+    org, dr = _mesh_rays(np.concatenate([m1[0], m2[0]]), 12000, seed=5)
+    assert_hits_equal(plain.intersect(org, dr), g.intersect(org, dr), "treelet order")
+    cam = host.camera_default(64, 48)
+    ia, sa = plain.render(cam, 64, 48, 4, seed=2)
+    ib, sb = g.render(cam, 64, 48, 4, seed=2)
+    assert np.array_equal(_bits(ia), _bits(ib)) and (sa.rays, sa.nodes) == (sb.rays, sb.nodes)
+    p1, n1 = _deformed(m1[0], m1[1], 21, 0.6)
+    p2, n2 = _deformed(m2[0], m2[1], 22, 0.3)
+    for s in (plain, g):
+        s.refit(np.concatenate([p1, p2]), np.concatenate([n1, n2]))
+        s.verify()
+    d1, keep1 = scenegen.random_objects(orc, 1, 3, 5, with_mesh=(p1, n1, m1[2]), second_mesh=(p2, n2, m2[2]))
+    o1 = orc.Scene.from_desc(d1, keep1)
+    org, dr = _mesh_rays(np.concatenate([p1, p2]), 8000, seed=6)
+    assert_hits_equal(o1.intersect(org, dr), g.intersect(org, dr), "treelet order, refitted")
+    plain.close(); g.close()

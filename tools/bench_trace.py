@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--w", type=int, default=960)
 ap.add_argument("--h", type=int, default=540)
 ap.add_argument("--spp", type=int, default=4)
+ap.add_argument("--only", default="", help="cornell | kd: one of the two scenes")
 a = ap.parse_args()
 api.init(0)
 w, h, spp = a.w, a.h, a.spp
@@ -27,8 +28,14 @@ v = ((np.repeat(ys.ravel(), spp) + rng.random(pix.size)) / h).astype(np.float32)
 org, d = api.generate_rays(host.camera_default(w, h), u, v)
 d = api.normalize_dirs(d)
 desc, keep = scenegen.random_objects(api, n_spheres=60, n_squares=30, seed=7)
-for name, g in (("cornell", host.HostScene.builtin(2).upload()), ("kd 60+30", api.DeviceScene(desc, keep=keep))):
-    for i in range(3):
+for name, make in (("cornell", lambda: host.HostScene.builtin(2).upload()), ("kd 60+30", lambda: api.DeviceScene(desc, keep=keep))):
+    if a.only and not name.startswith(a.only):
+        continue
+    g = make()
+    best = None
+    for i in range(5):
         _, st = g.trace(org, d, pix, smp)
+        best = st if best is None or st.kernel_ms < best.kernel_ms else best
+    st = best
     print(f"{name}: {len(org)} paths, {st.rays} rays, k_trace {st.kernel_ms:.3f} ms, {st.rays / st.kernel_ms / 1e6:.2f} Grays/s", flush=True)
     g.close()
