@@ -326,18 +326,20 @@ RT_DEV int bvh4_order(const DBvh4Q& n, f3 o, f3 id, float limit, int& e0, int& e
     /* entry / exit distance along an axis of a bound stored as code q: ((lo + q scale) - o) id = q (scale id) + (lo - o) id */
     const f3 A = mk3(n.scale[0] * id.x, n.scale[1] * id.y, n.scale[2] * id.z);
     const f3 B = mk3((n.lo[0] - o.x) * id.x, (n.lo[1] - o.y) * id.y, (n.lo[2] - o.z) * id.z);
+    /* Which face of a box the ray meets first along an axis is the sign of its direction there (A has that sign, or is zero and
+     * both faces give B; the factors are finite, see bvh_inv, so no NaN can arise): the near and the far codes of all four
+     * children are picked once per axis instead of ordering every pair of distances. */
+    const bool px = id.x >= 0.f, py = id.y >= 0.f, pz = id.z >= 0.f;
+    const uint32_t nx = px ? n.q[0] : n.q[3], fx = px ? n.q[3] : n.q[0];
+    const uint32_t ny = py ? n.q[1] : n.q[4], fy = py ? n.q[4] : n.q[1];
+    const uint32_t nz = pz ? n.q[2] : n.q[5], fz = pz ? n.q[5] : n.q[2];
     float tn[4];
     bool h[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         auto code = [&](uint32_t w) { return (float)((w >> (8 * k)) & 255u); }; /* byte k of w as a float: one v_cvt_f32_ubyte<k> */
-        const float x1 = __builtin_fmaf(code(n.q[0]), A.x, B.x), x2 = __builtin_fmaf(code(n.q[3]), A.x, B.x);
-        const float y1 = __builtin_fmaf(code(n.q[1]), A.y, B.y), y2 = __builtin_fmaf(code(n.q[4]), A.y, B.y);
-        const float z1 = __builtin_fmaf(code(n.q[2]), A.z, B.z), z2 = __builtin_fmaf(code(n.q[5]), A.z, B.z);
-        /* fminf / fmaxf drop a NaN operand (0 * inf when the ray runs inside a face plane): that axis then does not constrain
-         * the interval, which is the conservative reading (as in slab) */
-        tn[k] = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.f));
-        const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), limit));
+        tn[k] = fmaxf(fmaxf(__builtin_fmaf(code(nx), A.x, B.x), __builtin_fmaf(code(ny), A.y, B.y)), fmaxf(__builtin_fmaf(code(nz), A.z, B.z), 0.f));
+        const float tf = fminf(fminf(__builtin_fmaf(code(fx), A.x, B.x), __builtin_fmaf(code(fy), A.y, B.y)), fminf(__builtin_fmaf(code(fz), A.z, B.z), limit));
         h[k] = tn[k] <= tf && n.child[k] != RT_BVH4Q_EMPTY;
     }
     e0 = n.child[0]; e1 = n.child[1]; e2 = n.child[2]; e3 = n.child[3];

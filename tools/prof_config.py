@@ -18,11 +18,12 @@ ap.add_argument("--pass-spp", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--tile", type=int, default=16, help="tile edge (bench.py renders 8 x 8 tiles)")
+ap.add_argument("--build", default="auto", help="auto | host | device: who builds the triangle BVH")
 a = ap.parse_args()
 api.init(0)
 dev = torch.device("cuda", 0)
 wl = workloads.make(a.config)
-scene = wl.upload()
+scene = wl.upload({"auto": None, "host": 0, "device": api.BUILD_BVH_DEVICE}[a.build])
 w, h, spp = wl.w, wl.h, a.spp or wl.spp
 pass_spp = min(a.pass_spp or wl.pass_spp, spp)
 cam = wl.camera()
