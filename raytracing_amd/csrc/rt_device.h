@@ -142,6 +142,18 @@ struct Cnt { uint32_t rays, nodes; uint32_t* stack; uint32_t bvh_nodes, bvh_tris
 /* kernel variants: bit 0 = the object kd-tree has internal nodes, bit 1 = some mesh has a triangle BVH.
  * Code a scene cannot reach is compiled out of its variant, which keeps the common variant's registers low. */
 #define RT_M_KD 1
+#ifdef RT_LANE_STATS /* debug build only: how many lanes run each marked region ([2 id] visits by a wave, [2 id + 1] lanes) */
+__device__ unsigned long long rt_dbg_lanes[64];
+#define RT_LANE_PROBE(id)                                                                                   \
+    do {                                                                                                    \
+        const unsigned long long probe_m = __ballot(1);                                                     \
+        if (__lane_id() == (unsigned)__builtin_ctzll(probe_m)) {                                             \
+            atomicAdd(&rt_dbg_lanes[2 * (id)], 1ull); atomicAdd(&rt_dbg_lanes[2 * (id) + 1], (unsigned long long)__popcll(probe_m)); \
+        }                                                                                                   \
+    } while (0)
+#else
+#define RT_LANE_PROBE(id) do {} while (0)
+#endif
 #define RT_M_BVH 2
 #define RT_STACK_LDS 32      /* entries per lane, all in LDS: the host bounds the BVH depth to this (kBvhMaxDepth) */
 #define RT_STACK_STRIDE 256  /* workgroup size of the lane-per-ray kernels: lane-interleaved, conflict-free LDS layout */
@@ -650,6 +662,7 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
 /* ---- Scene::computeIntersection, R/src/Scene.h:169-205 via KDTree::intersect :679-687 ----- */
 template <int M>
 RT_DEV HitRec closest_rec(const DeviceScene& sc, f3 o, f3 d, Cnt& cnt) {
+    RT_LANE_PROBE(9);
     ++cnt.rays;
     HitRec best;
     best.t = RT_INF; best.type = -1; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
@@ -735,6 +748,7 @@ RT_DEV uint32_t sample_rules(const SquareRules& rules, const float (&bu)[SB], co
     uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)rules.by_sample);
     if (!left) return test;
     auto one = [&](const DLightSq& t, uint32_t k) {
+        RT_LANE_PROBE(2);
         const int flip = ((rules.flipped >> k) & 1u) ? (int)0x80000000 : 0;
         const float h0 = __int_as_float(__float_as_int(t.h0) ^ flip), e1 = __int_as_float(__float_as_int(t.e1) ^ flip),
                     e2 = __int_as_float(__float_as_int(t.e2) ^ flip);
@@ -789,6 +803,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
     if (0)
 #endif
     for_each_record(sc.spheres, sc.n_spheres, [&](const DSphere& s, uint32_t si) {
+        RT_LANE_PROBE(3);
         f3 oc = o - ld3(s.c);
         float c; /* |o - c|^2 - r^2 depends on the origin only: the caller computed it for the first spheres (sphere_c) */
         if (si < RT_SPH_KEPT) {
@@ -808,6 +823,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
             some = some || delta[j] >= 0.f;
         }
         if (!some) return; /* every line of the batch misses the sphere */
+        RT_LANE_PROBE(4);
 #ifndef RT_NO_SPHERE_CERT
         /* A line that meets the sphere is not yet a ray that meets it before the light: rays that leave the sphere they start
          * on, and rays whose line reaches a sphere only behind their origin or beyond the light, are most of the lines that get
@@ -835,6 +851,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
             float a = dot3(d[j], d[j]);
             float t = RT_INF; /* stays +inf (never < dist) when the sphere is missed */
             if (delta[j] > 0.f) {
+                RT_LANE_PROBE(5);
                 float sq = __builtin_sqrtf(delta[j]);
                 float a2 = 2.f * a;
                 float t1 = (-b[j] - sq) / a2, t2 = (-b[j] + sq) / a2;
@@ -857,6 +874,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
 #pragma unroll
     for (int j = 0; j < SB; ++j) dist_hi[j] = dist[j] * 1.000001f;
     auto square = [&](const DSquare& q, uint32_t) {
+        RT_LANE_PROBE(6);
         f3 v0 = ld3(q.v0), n = ld3(q.n);
         float num = dot3(v0 - o, n);
         bool maybe[SB], some = false;
@@ -870,6 +888,7 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
 #pragma unroll
         for (int j = 0; j < SB; ++j)
             if (maybe[j]) {
+                RT_LANE_PROBE(7);
                 float tt = num / dot3(d[j], n);
                 if (tt >= 0.f && tt < dist[j] && square_in_rect(q, (o + tt * d[j]) - v0)) occ[j] = true;
             }
@@ -1240,6 +1259,7 @@ __device__ unsigned long long rt_dbg_hist[65];
 template <int M, int SB = RT_SB>
 RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     static_assert(16 % SB == 0, "the 16 light samples of a quad light come in whole batches");
+    RT_LANE_PROBE(0);
     ++cnt.nodes;
 #ifdef RT_SHADE_HIST
     { /* the predicate depends on per-lane data so that the ballot cannot be moved out of the (divergent) path loop */
@@ -1305,6 +1325,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                  * are added after the walks, their light directions rebuilt from the random stream. */
                 uint32_t first_open = 16; /* wave-uniform: the first sample whose light term is still to be added */
                 for (int i0 = 0; i0 < 16; i0 += SB) {
+                    RT_LANE_PROBE(1);
                     f3 L[SB], Ld[SB];
                     float dist[SB], bu[SB], bv[SB];
                     bool occ[SB];
@@ -1359,7 +1380,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                     if (now) {
 #pragma unroll
                         for (int j = 0; j < SB; ++j)
-                            if (!occ[j]) light_term(sum, lt, m, N, V, L[j], all16);
+                            if (!occ[j]) { RT_LANE_PROBE(8); light_term(sum, lt, m, N, V, L[j], all16); }
                     }
                 }
                 if ((M & RT_M_BVH) && first_open < 16) {
@@ -1404,6 +1425,7 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
  * R/src/Scene.h:369-370 via :259-260; none for a point light) and the work counters, which keep counting what
  * the reference does -- the shadow queries not traced are reported separately in `skipped`. */
 RT_DEV void skip_shade(const DeviceScene& sc, Rng& rng, Cnt& cnt) {
+    RT_LANE_PROBE(11);
     ++cnt.nodes;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const uint32_t n = ldc(&sc.lights[li].type) == RT_LIGHT_QUAD ? 16u : 1u;
@@ -1418,6 +1440,7 @@ RT_DEV void skip_shade(const DeviceScene& sc, Rng& rng, Cnt& cnt) {
  * kind 2: glass without a refracted ray (total internal reflection, or F rounds to 1).  mtype is RT_MAT_MIRROR or RT_MAT_GLASS. */
 struct Bounce { f3 ro, rd, to, td; float F; uint32_t kind; };
 RT_DEV Bounce bounce_rays(const DeviceScene& sc, int mtype, int mat, f3 P, f3 N, f3 I) {
+    RT_LANE_PROBE(10);
     Bounce b;
     b.to = b.td = mk3(0.f, 0.f, 0.f);
     b.F = 0.f;

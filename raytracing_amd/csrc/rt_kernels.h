@@ -524,6 +524,12 @@ extern "C" int rt_debug_walk_stats(unsigned long long* out128, int reset) {
     return hipMemcpyFromSymbol(out128, HIP_SYMBOL(rt_dbg_walk), 128 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef RT_LANE_STATS
+extern "C" int rt_debug_lane_stats(unsigned long long* out64, int reset) {
+    if (reset) { unsigned long long z[64] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_lanes), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(rt_dbg_lanes), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef RT_SHADE_HIST
 extern "C" int rt_debug_shade_hist(unsigned long long* out65, int reset) {
     if (reset) { unsigned long long z[65] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(rt_dbg_hist), z, sizeof(z)) == hipSuccess ? 0 : -1; }
