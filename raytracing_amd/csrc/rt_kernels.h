@@ -132,6 +132,11 @@ RT_DEV void flush_counters(uint64_t* counters, const Cnt& c, uint32_t samples) {
 #ifndef RT_MIN_WAVES0
 #define RT_MIN_WAVES0 6
 #endif
+/* Scenes with a triangle BVH and a root leaf (mode 2) also take batches of two, at their four waves: a third of the register
+ * spills (29 against 68 VGPRs), 1 M-triangle frame 587 -> 581 ms, 10 M-triangle frame in four passes 74.7 -> 71.4 ms. */
+#ifndef RT_SB2
+#define RT_SB2 2
+#endif
 #ifndef RT_FRAME_LDS0
 #define RT_FRAME_LDS0 3
 #endif
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
      * 4 waves / SIMD = 16 waves per CU each wave can have 10 KB of the CU's 160 KB; the variants that traverse a BVH
      * need their LDS for the traversal stack and keep the frames in the per-lane array */
     constexpr int L = (M & RT_M_BVH) ? 0 : (M == 0 ? RT_FRAME_LDS0 : RT_FRAME_LDS);
-    constexpr int SB = M == 0 ? RT_SB0 : RT_SB;
+    constexpr int SB = M == 0 ? RT_SB0 : (M == RT_M_BVH ? RT_SB2 : RT_SB);
     __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 64 * RT_RENDER_WAVES : 1];
     Cnt cnt = new_cnt(s_stack + threadIdx.x, 64 * RT_RENDER_WAVES, s_frames + (L ? threadIdx.x : 0), 64 * RT_RENDER_WAVES);
     uint32_t my_samples = 0;
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 0 ? RT
     __shared__ uint32_t s_stack[RT_STACK_LDS * RT_STACK_STRIDE];
     /* the first levels of the path-frame stack in LDS where no BVH stack needs it */
     constexpr int L = (M & RT_M_BVH) ? 0 : (M == 0 ? RT_KTRACE_FRAMES0 : RT_FRAME_LDS);
-    constexpr int SB = M == 0 ? RT_KTRACE_SB0 : RT_SB;
+    constexpr int SB = M == 0 ? RT_KTRACE_SB0 : (M == RT_M_BVH ? RT_SB2 : RT_SB);
     __shared__ float s_frames[L ? L * RT_FRAME_WORDS * 256 : 1];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Cnt cnt = new_cnt(s_stack + threadIdx.x, RT_STACK_STRIDE, s_frames + (L ? threadIdx.x : 0), 256);
