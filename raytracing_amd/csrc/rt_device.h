@@ -155,7 +155,9 @@ __device__ unsigned long long rt_dbg_lanes[64];
 #define RT_LANE_PROBE(id) do {} while (0)
 #endif
 #define RT_M_BVH 2
+#ifndef RT_STACK_LDS
 #define RT_STACK_LDS 32      /* entries per lane, all in LDS: the host bounds the BVH depth to this (kBvhMaxDepth) */
+#endif
 #define RT_STACK_STRIDE 256  /* workgroup size of the lane-per-ray kernels: lane-interleaved, conflict-free LDS layout */
 
 /* wave-level helpers: number of set bits of `mask` below `lane`; ordering of this wave's LDS accesses (the LDS
@@ -331,7 +333,7 @@ RT_DEV bool bvh_reaches(const DMesh& m, f3 o, f3 d, float limit) {
 /* The traversal proper; the caller has checked bvh_reaches.  It walks the four-wide tree in its 64-byte form (DBvh4Q): one
  * fetch of four dwordx4 decides among four subtrees, the hit ones are visited nearest first.  Stack: RT_STACK_LDS entries in LDS, and what a
  * path could need beyond them (three pushes per level, RT_STACK_LDS / 2 levels at most) in a small per-lane array. */
-#define RT_STACK_OVER (RT_STACK_LDS / 2)
+#define RT_STACK_OVER 16 /* a power of two: the index wraps by masking */
 /* The four child boxes of a wide node against a ray: how many the ray reaches within `limit`, and their stack entries
  * (>= 0 inner node, < 0 leaf) ordered by entry distance, e0 the nearest. */
 RT_DEV int bvh4_order(const DBvh4Q& n, f3 o, f3 id, float limit, int& e0, int& e1, int& e2, int& e3) {
