@@ -958,12 +958,16 @@ RT_DEV void shadow_batch(const DeviceScene& sc, f3 o, bool o_inside, const f3 (&
 
 /* ---- random numbers ---------------------------------------------------------------------- */
 struct Rng {
-    uint32_t key, k;
+    /* kg = k * 0x9E3779B9 mod 2^32 for the stream position k: draw k is rt_mix32(key + kg) >> 1 = rt_rand31(key, k), and
+     * moving on in the stream is one addition instead of a multiplication per draw */
+    uint32_t key, kg;
+    RT_DEV void at(uint32_t k) { kg = k * 0x9E3779B9U; }
+    RT_DEV void skip(uint32_t n) { kg += n * 0x9E3779B9U; }
     /* (float)rand() / RAND_MAX with RAND_MAX converted to float = 2^31 (R/src/Scene.h:259-260) */
-#ifdef RT_EXP_CHEAP_RNG /* attribution: what the three integer multiplies and six shift / xor steps of a draw cost */
-    RT_DEV float unit() { return (float)(int)(((key + (k++) * 0x9E3779B9U) ^ 0x5bd1e995U) >> 1) / 2147483648.f; }
+#ifdef RT_EXP_CHEAP_RNG /* attribution: what the two integer multiplies and six shift / xor steps of a draw cost */
+    RT_DEV float unit() { const float r = (float)(int)(((key + kg) ^ 0x5bd1e995U) >> 1) / 2147483648.f; kg += 0x9E3779B9U; return r; }
 #else
-    RT_DEV float unit() { return (float)(int)rt_rand31(key, k++) / 2147483648.f; }
+    RT_DEV float unit() { const float r = (float)(int)(rt_mix32(key + kg) >> 1) / 2147483648.f; kg += 0x9E3779B9U; return r; }
 #endif
 };
 
@@ -971,7 +975,7 @@ struct Rng {
  * k + 2 i + 1 of the sample's random stream, wherever the caller is in that stream. */
 RT_DEV f3 light_sample(const Rng& at_first, uint32_t i, f3 p0, f3 p1, f3 p2) {
     Rng r = at_first;
-    r.k += 2u * i;
+    r.skip(2u * i);
     float u = r.unit();
     float v = r.unit();
     if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
@@ -1074,7 +1078,7 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
     row(R_START, my) = start; row(R_NEAR, my) = near;
     row(R_PX, my) = __float_as_uint(P.x); row(R_PY, my) = __float_as_uint(P.y); row(R_PZ, my) = __float_as_uint(P.z);
     row(R_OX, my) = __float_as_uint(o.x); row(R_OY, my) = __float_as_uint(o.y); row(R_OZ, my) = __float_as_uint(o.z);
-    row(R_KEY, my) = at_first.key; row(R_K, my) = at_first.k;
+    row(R_KEY, my) = at_first.key; row(R_K, my) = at_first.kg;
     if (my == 0) row(R_NEXT, 0) = n_lanes; /* rays 0 .. n_lanes - 1 are handed out by position */
     wave_lds_sync();
     bool want = true, out_of_rays = false, first = true;
@@ -1137,7 +1141,7 @@ RT_DEV uint32_t walk_deferred(const DeviceScene& sc, f3 P, f3 o, const Rng& at_f
                     owner = c | (i << 8);
                     const f3 Pc = mk3(__uint_as_float(row(R_PX, c)), __uint_as_float(row(R_PY, c)), __uint_as_float(row(R_PZ, c)));
                     ro = mk3(__uint_as_float(row(R_OX, c)), __uint_as_float(row(R_OY, c)), __uint_as_float(row(R_OZ, c)));
-                    Rng r0; r0.key = row(R_KEY, c); r0.k = row(R_K, c);
+                    Rng r0; r0.key = row(R_KEY, c); r0.kg = row(R_K, c);
                     rd = norm3_unit(norm3_len(light_sample(r0, i, p0, p1, p2) - Pc, rdist));
                     id = bvh_inv_dir(rd);
                     want = !next_mesh(0); /* a ray that comes near no mesh after all is answered: not hit */
@@ -1431,7 +1435,7 @@ RT_DEV void skip_shade(const DeviceScene& sc, Rng& rng, Cnt& cnt) {
     ++cnt.nodes;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const uint32_t n = ldc(&sc.lights[li].type) == RT_LIGHT_QUAD ? 16u : 1u;
-        if (n == 16u) rng.k += 32u;
+        if (n == 16u) rng.skip(32u);
         cnt.rays += n;
         cnt.skipped += n;
     }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(T) void k_tile_class(DeviceScene sc, const DCamera*
         f3 o, d;
         primary_ray(*cam, u, v, o, d);
         Cnt cnt = new_cnt(s_stack + threadIdx.x, T);
-        Rng rng; rng.key = 0; rng.k = 0;
+        Rng rng; rng.key = 0; rng.at(0);
         (void)trace_path<P, true>(sc, o, norm3(d), rng, cnt);
         return cnt.nodes;
     };
@@ -300,7 +300,7 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
     if (lane < n_samples) {
         uint32_t pixel, smp;
         sample_of(f_first + lane, pixel, smp);
-        Rng rng; rng.key = rt_rng_key(rp.seed, pixel, smp); rng.k = 0;
+        Rng rng; rng.key = rt_rng_key(rp.seed, pixel, smp); rng.at(0);
         float u = ((float)(int)(pixel % rp.w) + rng.unit()) / (float)(int)rp.w;
         float v = ((float)(int)(pixel / rp.w) + rng.unit()) / (float)(int)rp.h;
         f3 o, d;
@@ -340,7 +340,7 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
                             kind = 2 + bn.kind;
                             nchild = bn.kind == 1u ? 2u : 1u;
                             if (mtype == RT_MAT_GLASS) { /* its Phong colour is never used: only what Scene::phong would have counted */
-                                Rng none; none.key = 0; none.k = 0;
+                                Rng none; none.key = 0; none.at(0);
                                 skip_shade(sc, none, cnt);
                             }
                         }
@@ -420,7 +420,7 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
             sample_of(f_first + (meta >> 8), pixel, smp);
             Rng rng;
             rng.key = rt_rng_key(rp.seed, pixel, smp);
-            rng.k = 2u + draws_per_node * fld(TF_PRE, i);
+            rng.at(2u + draws_per_node * fld(TF_PRE, i));
             put3(TF_A0, i, shade<M>(sc, h, rng, cnt));
         }
     }
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
         const uint32_t first_lane = sub * rp.spp, s = rp.sample0 + (lane - first_lane);
         f3 col = mk3(0.f, 0.f, 0.f);
         if (in_image) {
-            Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.k = 0;
+            Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.at(0);
             float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
             float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
             f3 o, d;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64 * RT_RENDER_WAVES, (M == 0 ? RT_MIN_WAVES0 : RT_
             const uint32_t s = rp.sample0 + s0 + lane;
             f3 col = mk3(0.f, 0.f, 0.f);
             if (s0 + lane < rp.spp) {
-                Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.k = 0;
+                Rng rng; rng.key = rt_rng_key(rp.seed, x + y * rp.w, s); rng.at(0);
                 /* R/main.cpp:186-187 */
                 float u = ((float)(int)x + rng.unit()) / (float)(int)rp.w;
                 float v = ((float)(int)y + rng.unit()) / (float)(int)rp.h;
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 0 ? RT
     uint32_t smp = 0;
     if (i < n) {
         f3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i); /* a Ray's direction() is already unit length */
-        Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.k = k0;
+        Rng rng; rng.key = rt_rng_key(seed, pixel[i], sample[i]); rng.at(k0);
         f3 c = trace_path<M, false, L, SB>(sc, o, d, rng, cnt);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
         smp = 1;
