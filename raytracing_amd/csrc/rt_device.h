@@ -493,30 +493,27 @@ RT_DEV bool square_surely_behind(const DSquare& q, f3 o, f3 d) {
 }
 
 /* ---- leaf loop of KDTree::intersectNode, R/src/KDTree.cpp:586-598 ------------------------
- * One object of a leaf against one ray: the object's own intersect routine behind the certain-miss tests. */
-template <int M>
-RT_DEV bool leaf_object(const DeviceScene& sc, int type, int object, const DSphere& s, const DSquare& q, f3 o, f3 d, Cnt& cnt,
-                        float& t, int& tri, float& u, float& v) {
-    if (type == RT_SPHERE) return !sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t);
-    if (type == RT_SQUARE) return !square_surely_behind(q, o, d) && square_t(q, o, d, t);
-    return mesh_closest<M>(sc, ldc(&sc.meshes[object]), o, d, cnt, t, tri, u, v);
-}
+ * The references of a leaf keep the order of KDTree::buildKDTree's list -- spheres, squares, meshes (every split is a stable
+ * partition) -- so a leaf is walked in two parts: its spheres and squares (by each lane for itself, or by the wave together
+ * from scalar-loaded records), then its meshes from `meshes_at` on, in one place for both (kd_closest). */
 RT_DEV void leaf_keep(HitRec& best, int type, int object, float t, int tri, float u, float v) {
     if (best.type < 0 || t < best.t) { best.t = t; best.type = type; best.obj = object; best.tri = tri; best.u = u; best.v = v; }
 }
 /* Every lane walks the references of its own leaf (the lanes of the wave may be in different leaves: vector loads). */
-template <int M>
-RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, Cnt& cnt, HitRec& best) {
+RT_DEV bool leaf_closest(const DeviceScene& sc, int first, int count, f3 o, f3 d, HitRec& best, int& meshes_at) {
     bool any = false;
-    for (int r = first; r < first + count; ++r) {
+    int r = first;
+    for (; r < first + count; ++r) {
         const DLeafRec* rec = &sc.leaf_recs[r];
         const int type = ldc(&rec->type), object = ldc(&rec->object);
-        float t = 0.f, u = 0.f, v = 0.f;
-        int tri = -1;
-        DSphere s; DSquare q;
-        if (type == RT_SPHERE) s = ldc(&rec->u.s); else if (type == RT_SQUARE) q = ldc(&rec->u.q);
-        if (leaf_object<M>(sc, type, object, s, q, o, d, cnt, t, tri, u, v)) { any = true; leaf_keep(best, type, object, t, tri, u, v); }
+        float t = 0.f;
+        bool ok;
+        if (type == RT_SPHERE) { const DSphere s = ldc(&rec->u.s); ok = !sphere_surely_missed(s, o, d) && sphere_t(s, o, d, t); }
+        else if (type == RT_SQUARE) { const DSquare q = ldc(&rec->u.q); ok = !square_surely_behind(q, o, d) && square_t(q, o, d, t); }
+        else break;
+        if (ok) { any = true; leaf_keep(best, type, object, t, -1, 0.f, 0.f); }
     }
+    meshes_at = r;
     return any;
 }
 /* The same loop for a scene whose root is a leaf (every built-in scene): the leaf list is all
@@ -578,14 +575,18 @@ RT_DEV bool leaf_any(const DeviceScene& sc, int first, int count, f3 o, f3 d, fl
 }
 /* The leaf loop for lanes that are all in the same leaf (first, count wave-uniform): the records arrive by scalar loads, each
  * requested while the one before it is tested, and the branch on the object's kind is the same for all lanes. */
-template <int M>
-RT_DEV bool leaf_closest_uniform(const DeviceScene& sc, int first, int count, f3 o, f3 d, Cnt& cnt, HitRec& best) {
+RT_DEV bool leaf_closest_uniform(const DeviceScene& sc, int first, int count, f3 o, f3 d, HitRec& best, int& meshes_at) {
     bool any = false;
-    for_each_record(sc.leaf_recs + first, (uint32_t)count, [&](const DLeafRec& rec, uint32_t) {
-        float t = 0.f, u = 0.f, v = 0.f;
-        int tri = -1;
-        if (leaf_object<M>(sc, rec.type, rec.object, rec.u.s, rec.u.q, o, d, cnt, t, tri, u, v)) { any = true; leaf_keep(best, rec.type, rec.object, t, tri, u, v); }
+    int at = first + count;
+    for_each_record(sc.leaf_recs + first, (uint32_t)count, [&](const DLeafRec& rec, uint32_t i) {
+        float t = 0.f;
+        bool ok;
+        if (rec.type == RT_SPHERE) ok = !sphere_surely_missed(rec.u.s, o, d) && sphere_t(rec.u.s, o, d, t);
+        else if (rec.type == RT_SQUARE) ok = !square_surely_behind(rec.u.q, o, d) && square_t(rec.u.q, o, d, t);
+        else { at = min(at, first + (int)i); return; }
+        if (ok) { any = true; leaf_keep(best, rec.type, rec.object, t, -1, 0.f, 0.f); }
     });
+    meshes_at = at;
     return any;
 }
 
@@ -631,14 +632,22 @@ RT_DEV bool kd_closest(const DeviceScene& sc, f3 o, f3 d, float t_in, float t_ou
         const int lead_first = __builtin_amdgcn_readlane(first, lead), lead_count = __builtin_amdgcn_readlane(count, lead);
         const bool with_lead = !done && node == lead_node;
         bool tested;
+        int meshes_at = 0;
         if (2 * __popcll(__ballot(with_lead)) >= __popcll(waiting)) {
             tested = with_lead;
-            if (with_lead) ret = leaf_closest_uniform<M>(sc, lead_first, lead_count, o, d, cnt, best);
+            if (with_lead) ret = leaf_closest_uniform(sc, lead_first, lead_count, o, d, best, meshes_at);
         } else {
             tested = !done;
-            if (!done) ret = leaf_closest<M>(sc, first, count, o, d, cnt, best);
+            if (!done) ret = leaf_closest(sc, first, count, o, d, best, meshes_at);
         }
         if (!tested) continue;
+        if (sc.n_meshes) /* the leaf's meshes, last in its list */
+            for (int r = meshes_at; r < first + count; ++r) {
+                const int object = ldc(&sc.leaf_recs[r].object);
+                float t = 0.f, u = 0.f, v = 0.f;
+                int tri = -1;
+                if (mesh_closest<M>(sc, ldc(&sc.meshes[object]), o, d, cnt, t, tri, u, v)) { ret = true; leaf_keep(best, RT_MESH, object, t, tri, u, v); }
+            }
         bool resumed = false;
         while (sp > 0) { /* hand `ret` back to the waiting levels */
             int k = sp - 1;
