@@ -1292,10 +1292,10 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
     const bool all16 = __ballot(m.shininess != 16.0f) == 0ull; /* decided once per shaded point for the whole wave */
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const DLight lt = ldc(&sc.lights[li]);
-        if (lt.type == RT_LIGHT_QUAD) {
+        if (lt.type == RT_LIGHT_QUAD && !(M & RT_M_KD)) {
             f3 sum = mk3(0.f, 0.f, 0.f);
             f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
-            if (!(M & RT_M_KD)) {
+            {
                 const bool so_inside = inside_box(sc.box_lo, sc.box_hi, so);
                 const Rng at_first = rng; /* the stream position of light sample 0 */
                 /* What this point's shadow rays still have to test of every square (SquareRules, DLightSq).  The side of a
@@ -1410,25 +1410,39 @@ RT_DEV f3 shade(const DeviceScene& sc, const FullHit& h, Rng& rng, Cnt& cnt) {
                         light_term(sum, lt, m, N, V, norm3_len(light_sample(at_first, i, p0, p1, p2) - P, len));
                     }
                 }
-            } else
-                for (int i = 0; i < 16; ++i) {
-                    float u = rng.unit();
-                    float v = rng.unit();
-                    if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
-                    f3 S = ((1.f - u - v) * p0 + u * p1) + v * p2;
-                    f3 SP = S - P;
-                    f3 L = norm3(SP);
-                    if (occluded<M>(sc, so, norm3_unit(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
-                    light_term(sum, lt, m, N, V, L);
-                }
+            }
             sum = sum / 16.f;
             diffuse = diffuse + sum;
             specular = specular + sum; /* the reference adds the quad-light term to both sums */
-        } else {
+        } else if (!(M & RT_M_KD)) { /* a point light */
             f3 SP = ld3(lt.pos) - P;
             f3 L = norm3(SP);
             if (occluded<M>(sc, so, norm3_unit(L), len3(SP), cnt)) continue;
             light_term(diffuse, lt, m, N, V, L);
+        } else {
+            /* kd-tree with internal nodes: one shadow query at a time, through one place in the code (the traversal is large):
+             * a point light (its term goes straight into the diffuse sum), or the 16 samples of a quad light (sum / 16 into both). */
+            const bool quad = lt.type == RT_LIGHT_QUAD;
+            const f3 p0 = ld3(lt.p0), p1 = ld3(lt.p1), p2 = ld3(lt.p2);
+            f3 acc = quad ? mk3(0.f, 0.f, 0.f) : diffuse;
+            for (int i = 0; i < (quad ? 16 : 1); ++i) {
+                f3 S = ld3(lt.pos);
+                if (quad) {
+                    float u = rng.unit();
+                    float v = rng.unit();
+                    if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+                    S = ((1.f - u - v) * p0 + u * p1) + v * p2;
+                }
+                f3 SP = S - P;
+                f3 L = norm3(SP);
+                if (occluded<M>(sc, so, norm3_unit(L), len3(SP), cnt)) continue; /* Ray() normalises L again */
+                light_term(acc, lt, m, N, V, L);
+            }
+            if (quad) {
+                acc = acc / 16.f;
+                diffuse = diffuse + acc;
+                specular = specular + acc; /* the reference adds the quad-light term to both sums */
+            } else diffuse = acc;
         }
     }
     return (ambient + diffuse) + specular;
