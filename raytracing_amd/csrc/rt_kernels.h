@@ -376,6 +376,9 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
     }
     const uint32_t n_nodes = le, n_levels = depth; /* level l = nodes [s_lv[l], s_lv[l + 1]), s_lv[n_levels] = n_nodes */
     wave_lds_sync();
+#ifdef RT_WAVE_TIMES
+    const unsigned long long t_expanded = wall_clock64();
+#endif
     /* 2. hit nodes per subtree, deepest level first */
     for (uint32_t l = n_levels; l-- > 0;) {
         const uint32_t b = s_lv[l], e = s_lv[l + 1];
@@ -454,11 +457,12 @@ RT_DEV bool tree_batch(const DeviceScene& sc, const DCamera* __restrict__ cam, c
     }
     tree_sync(); /* the next batch overwrites the tree */
 #ifdef RT_WAVE_TIMES
-    if (lane == 0) { s_lv[14] = n_nodes; s_lv[15] = n_list; }
+    if (lane == 0) { s_lv[14] = n_nodes; s_lv[15] = n_list; s_lv[13] = (uint32_t)t_expanded; }
 #endif
     return true;
 }
 #ifdef RT_WAVE_TIMES /* debug build only: start / end clock of every wave of k_render */
+RT_DEV uint32_t t_expanded_of(const uint32_t* s_lv) { return s_lv[13]; }
 __device__ unsigned long long* rt_dbg_times;
 __device__ unsigned long long* rt_dbg_items; /* behind the wave records: one record per worker batch */
 extern "C" int rt_debug_wave_times(unsigned long long* d_buf) {
@@ -506,10 +510,10 @@ RT_DEV uint32_t tree_worker(const DeviceScene& sc, const DCamera* __restrict__ c
 #endif
             if (tree_batch<M>(sc, cam, pass, mem, s_lv, dl, f0, n, draws, cnt)) {
 #ifdef RT_WAVE_TIMES
-                if (lane == 0 && rt_dbg_items) { /* one record per batch: start, end, nodes | shaded << 16 | samples << 32 | worker << 40 */
+                if (lane == 0 && rt_dbg_items) { /* one record per batch: start, end, nodes | shaded << 16 | samples << 32 | ticks of the expansion << 40 */
                     unsigned long long* rec = rt_dbg_items + 3ull * (f0 / (RT_TREE_BATCH / 2));
                     rec[0] = b_start; rec[1] = wall_clock64();
-                    rec[2] = (unsigned long long)s_lv[14] | ((unsigned long long)s_lv[15] << 16) | ((unsigned long long)n << 32) | ((unsigned long long)worker << 40);
+                    rec[2] = (unsigned long long)s_lv[14] | ((unsigned long long)s_lv[15] << 16) | ((unsigned long long)n << 32) | ((unsigned long long)(((uint32_t)t_expanded_of(s_lv) - (uint32_t)b_start) & 0xffffffu) << 40); /* ticks until the tree was expanded */
                 }
 #endif
                 f0 += n;

@@ -80,8 +80,10 @@ if a.wave_times:
             print(f"rank {rank}: {len(it)} worker batches of {np.bincount(ns).nonzero()[0].tolist()} samples; us per batch 50/90/99/max "
                   f"{[round(float(x)) for x in np.percentile(idur, (50, 90, 99, 100))]}; nodes per batch 50/90/99/max {[int(x) for x in np.percentile(nodes, (50, 90, 99, 100))]}; "
                   f"shaded {[int(x) for x in np.percentile(shaded, (50, 90, 99, 100))]}; us per node {idur.sum() / nodes.sum():.2f}; corr(us, nodes) {np.corrcoef(idur, nodes)[0, 1]:.2f}")
+            iexp = ((it[:, 2] >> 40) & 0xffffff) / 100.0   # us until the tree was expanded (closest hits); the rest is shading
+            print(f"   expansion share of the batch time: all batches {iexp.sum() / idur.sum() * 100:.0f} %, the slowest tenth {iexp[idur > np.percentile(idur, 90)].sum() / idur[idur > np.percentile(idur, 90)].sum() * 100:.0f} %")
             for i in np.argsort(-(ist + idur))[:8]:
-                print(f"   batch ends {ist[i] + idur[i]:.0f} us  started {ist[i]:.0f}  ran {idur[i]:.0f} us  {nodes[i]} nodes, {shaded[i]} shaded, {ns[i]} samples, worker {it[i, 2] >> 40}")
+                print(f"   batch ends {ist[i] + idur[i]:.0f} us  started {ist[i]:.0f}  ran {idur[i]:.0f} us (expansion {iexp[i]:.0f})  {nodes[i]} nodes, {shaded[i]} shaded, {ns[i]} samples")
             late = ist > np.percentile(ist, 90)
             print(f"   the last tenth of the batches to start: start {ist[late].min():.0f} .. {ist[late].max():.0f} us, us per batch 50/max {np.percentile(idur[late], 50):.0f} / {idur[late].max():.0f}")
         t = t[((t[:, 2] >> 44) & 0xfffff) != 0xfffff]
