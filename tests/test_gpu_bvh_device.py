@@ -166,3 +166,29 @@ def test_rt_scene_create_builds_large_scenes_on_the_device():
     org, d = _mesh_rays(pos, 1500, seed=12)
     assert_hits_equal(host_built.intersect(org, d), auto.intersect(org, d), "auto (device) against host")
     auto.close(); host_built.close()
+
+
+def test_axis_parallel_rays_through_the_wide_tree():
+    """Directions with components of exactly +0, -0 and +-1: the inverse direction of the box tests is kept finite there,
+    and the hits must still be the brute-force loop's, from origins inside and outside the mesh's bounds."""
+    o, (pos, nrm, tri) = _pair(72, seed=6)
+    g = api.DeviceScene(o.desc, keep=o, flags=api.BUILD_BVH_DEVICE)
+    rng = np.random.default_rng(8)
+    n = 6000
+    axes = np.float32([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1],
+                       [1, 0, -0.0], [-0.0, -1, 0], [0, -0.0, 1]])
+    d = axes[rng.integers(0, len(axes), n)].copy()
+    planar = rng.integers(0, 3, n)                                  # a third of them: one zero component, two free ones
+    free = rng.normal(size=(n, 3)).astype(np.float32)
+    mix = rng.random(n) < 0.33
+    free[np.arange(n), planar] = 0.0
+    d[mix] = orc.normalize_dirs(free[mix])
+    tgt = pos[rng.integers(0, len(pos), n)]
+    org = (tgt - d * rng.uniform(0.0, 3.0, (n, 1)).astype(np.float32)).astype(np.float32)   # the line passes through a vertex
+    org[n // 2:] += rng.normal(scale=0.02, size=(n - n // 2, 3)).astype(np.float32)          # ... or close by
+    a = o.mesh_intersect(0, org, d)
+    b = g.mesh_intersect(0, org, d)
+    assert a["hit"].sum() > 500
+    assert_hits_equal(a, b, "axis-parallel rays, mesh")
+    assert_hits_equal(o.intersect(org, d), g.intersect(org, d), "axis-parallel rays, scene")
+    g.close()
