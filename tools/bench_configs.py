@@ -90,7 +90,7 @@ if a.wave_times:
         st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0   # us at 100 MHz
         dur = en - st
         wave_bvh = (t[:, 2] >> 44) & 0xfffff
-        print(f"rank {rank}: waves that fetched no BVH node at all: {int((wave_bvh == 0).sum())} of {len(t)} ({(wave_bvh == 0).mean() * 100:.1f} %), "
+        print(f"rank {rank}: waves that fetched fewer than 64 BVH nodes: {int((wave_bvh == 0).sum())} of {len(t)} ({(wave_bvh == 0).mean() * 100:.1f} %), "
               f"their share of the summed wave time {dur[wave_bvh == 0].sum() / dur.sum() * 100:.1f} %")
         print(f"rank {rank}: {len(t)} waves, launch span {en.max():.0f} us, sum of wave times / 4096 slots {dur.sum() / 4096:.0f} us, "
               f"mean wave {dur.mean():.1f} us, max {dur.max():.0f} us; percentiles 50/90/99/99.9: {[round(float(np.percentile(dur, q))) for q in (50, 90, 99, 99.9)]}")
